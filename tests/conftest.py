@@ -1,0 +1,43 @@
+"""pytest configuration: markers, shared fixtures, tolerances."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# fp64 tolerances, stated once and used everywhere
+TOL_KERNEL = 1e-13      # relative Frobenius error of one primitive vs the reference / oracle
+TOL_COEFF = 1e-10       # m x m coefficient matrices of the first iterations
+TOL_SOLUTION = 1e-8     # final X vs reference at well-conditioned configurations
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def rel_err(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    nb = np.linalg.norm(b.ravel())
+    return np.linalg.norm((a - b).ravel()) / (nb if nb > 0 else 1.0)
+
+
+def golden_files(pattern="*.npz"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    return oracle.Oracle()

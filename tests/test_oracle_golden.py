@@ -1,0 +1,113 @@
+"""The oracle (oracle/oracle.hpp) against fixtures produced by the unmodified reference.
+
+This is what pins the oracle: every primitive K1-K9, the two m x m factorizations, and the whole
+SBCGrQ solve (final iterate, iteration count, early iterates) are compared with values the
+reference itself computed (tests/golden/generate.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TOL_KERNEL, TOL_SOLUTION, golden_files, rel_err
+
+FULL = [f for f in golden_files() if "8x8x8x8" not in f]
+WITH_PRIMS = [f for f in FULL if "v1000" not in f]
+
+
+def _dims(g):
+    return [int(d) for d in g["dims"]]
+
+
+@pytest.mark.parametrize("path", WITH_PRIMS, ids=os.path.basename)
+def test_primitives_match_reference(orc, path):
+    g = np.load(path)
+    B, Y, M = g["B"], g["Y"], g["M"]
+    dims, mass = _dims(g), float(g["mass"])
+    assert rel_err(orc.dirac_apply(g["U"], dims, mass, B), g["op_B"]) < TOL_KERNEL
+    assert rel_err(orc.add_scalar(Y, B, 0.3), g["add_scalar_0p3"]) < TOL_KERNEL
+    assert rel_err(orc.rescale_add_scalar(Y, -1.0, B, 0.25), g["rescale_add_scalar_m1_0p25"]) < TOL_KERNEL
+    assert rel_err(orc.add_matrix(Y, B, M), g["add_matrix"]) < TOL_KERNEL
+    assert rel_err(orc.rescale_add_matrix(Y, M, B, 1.0), g["rescale_add_matrix_1"]) < TOL_KERNEL
+    assert rel_err(orc.hermitian_dot(Y, B), g["hermitian_dot_YB"]) < TOL_KERNEL
+    assert rel_err(orc.hermitian_dot(Y, Y), g["hermitian_dot_YY"]) < TOL_KERNEL
+    q, r = orc.thin_qr(Y)
+    assert rel_err(q, g["thinqr_Q"]) < TOL_KERNEL
+    assert rel_err(r, g["thinqr_R"]) < TOL_KERNEL
+    assert rel_err(orc.tri_solve_rhs(B, g["thinqr_R"]), g["tri_solve"]) < TOL_KERNEL
+    assert rel_err(orc.sub(Y, B), g["sub"]) < TOL_KERNEL
+    assert rel_err(orc.cholesky_upper(g["hermitian_dot_YY"]), g["chol_upper"]) < TOL_KERNEL
+    assert rel_err(orc.inverse(M), g["inverse_M"]) < 1e-12
+
+
+@pytest.mark.parametrize("path", WITH_PRIMS, ids=os.path.basename)
+def test_hermitian_dot_is_exactly_hermitian(orc, path):
+    # inc/fields.hpp:109-120: lower triangle computed, upper mirrored
+    g = np.load(path)
+    R = orc.hermitian_dot(g["Y"], g["B"])
+    assert np.array_equal(np.triu(R, 1), np.conj(np.tril(R, -1)).T)
+
+
+@pytest.mark.parametrize("path", FULL, ids=os.path.basename)
+def test_solver_matches_reference(orc, path):
+    g = np.load(path)
+    dims, mass, shifts = _dims(g), float(g["mass"]), list(g["shifts"])
+    s = orc.sbcgrq(g["U"], dims, mass, g["B"], shifts, float(g["eps"]), float(g["eps_shifts"]))
+    ref_it = int(g["iterations"])
+    # iteration count: exact at well-conditioned configs, +-2 % at mass = 1e-3 (Appendix F)
+    slack = max(1, int(0.02 * ref_it)) if mass < 0.01 else 1
+    assert abs(s["iterations"] - ref_it) <= slack
+    res = orc.true_residuals(g["U"], dims, mass, g["B"], shifts, s["X"])
+    # the reference's own acceptance test (test/solvers.cpp:116); shifts that retired early are
+    # only bounded by eps_shifts-driven accuracy, so test shift 0 strictly and the rest loosely
+    assert res[0].max() < 2 * float(g["eps"])
+    assert np.all(res < np.maximum(2 * float(g["eps"]), 4 * g["residuals"]))
+    if s["iterations"] == ref_it and mass >= 0.05:
+        assert rel_err(s["X"], g["X"]) < TOL_SOLUTION
+
+
+@pytest.mark.parametrize("path", [f for f in FULL if "v1000" not in f], ids=os.path.basename)
+def test_early_iterates_match_reference(orc, path):
+    g = np.load(path)
+    dims, mass, shifts = _dims(g), float(g["mass"]), list(g["shifts"])
+    k = 1
+    while f"X_after_{k}" in g.files:
+        s = orc.sbcgrq(g["U"], dims, mass, g["B"], shifts, 0.0, 0.0, max_iterations=k)
+        assert s["iterations"] == k
+        assert rel_err(s["X"], g[f"X_after_{k}"]) < 1e-12, k
+        k += 1
+    assert k > 1
+
+
+def test_summary_fixture_8x8x8x8(orc):
+    g = np.load(golden_files("ref4d_8x8x8x8_m4.npz")[0])
+    dims, mass, shifts = _dims(g), float(g["mass"]), list(g["shifts"])
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, int(g["seed_U"]))
+    B = orc.fill_field(4, V, int(g["seed_B"]))
+    assert rel_err(orc.dirac_apply(U, dims, mass, B)[:4], g["op_B_sites"]) < TOL_KERNEL
+    s = orc.sbcgrq(U, dims, mass, B, shifts, float(g["eps"]), float(g["eps_shifts"]))
+    assert abs(s["iterations"] - int(g["iterations"])) <= max(1, int(0.02 * int(g["iterations"])))
+    res = orc.true_residuals(U, dims, mass, B, shifts, s["X"])
+    assert res[0].max() < 2 * float(g["eps"])
+    coln = np.sqrt((np.abs(s["X"]) ** 2).sum(axis=(1, 3)))
+    assert rel_err(coln, g["X_colnorm"]) < 1e-6
+    assert rel_err(s["X"][:, :4], g["X_sites"]) < 1e-5
+
+
+def test_fixed_work_mode_runs_past_tolerance(orc):
+    # eps = eps_shifts = 0 with finite max_iterations is the benchmark mode
+    g = np.load(golden_files("ref4d_4x4x4x6_m4.npz")[0])
+    dims = _dims(g)
+    s = orc.sbcgrq(g["U"], dims, float(g["mass"]), g["B"], list(g["shifts"]), 0.0, 0.0, max_iterations=7, trace_limit=7)
+    assert s["iterations"] == 7
+    assert np.all(np.isfinite(s["trace"]["residual"])) and s["trace"]["residual"][-1] < 1.0
+    assert s["trace"]["alpha"].shape == (7, 4, 4)
+
+
+def test_generator_is_split_independent(orc):
+    whole = orc.fill_field(3, 40, 5)
+    part = orc.fill_field(3, 15, 5, first_global_site=25)
+    assert np.array_equal(whole[25:], part)
+    assert np.abs(whole.real).max() <= 1 and np.abs(whole.imag).max() <= 1
+    assert abs(whole.real.mean()) < 0.2
