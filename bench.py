@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- SBCGrQ iteration throughput on MI355X (BASELINE.json metric).
+
+A "step" is one SBCGrQ iteration (one pass of the loop body, inc/block_solvers.hpp:132-182) in
+fixed-work mode (eps = eps_shifts = 0: every shift stays active, work per iteration is constant).
+Workload at N = 1: BASELINE.json configs[2], V = 64^4, m = 16 right-hand sides, 4 shifts, fp64 --
+the largest configuration that fits one GPU (128^4 needs 2.4 TB).  For N > 1
+the lattice is domain-decomposed with 64^4 sites PER GPU (weak scaling; 8 GPUs = 64 x 128^3), one
+process per GPU, halo faces and the m x m all-reduce over torch.distributed / RCCL.
+
+Prints ONE JSON line on rank 0.  `value` = lattice-site iterations per second summed over all
+GPUs (iterations/s x global volume) with all inputs resident in HBM; iterations/s and the achieved
+algorithmic HBM GB/s are reported next to it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SHIFTS = [0.0, 1e-6, 1e-4, 1e-2, 1e-5, 1e-3, 1e-1, 1.0]  # SURVEY.md section 8d; first S, sorted
+MASS = 1e-3
+
+
+def kernel_bytes(name, V, m, S, ndim):
+    """Algorithmic HBM bytes of ONE launch of a kernel class ('Kernels'): s = 48 m bytes per
+    site of a field, g = 144 ndim bytes of links per site."""
+    s, g = 48.0 * m, 144.0 * ndim
+    table = {
+        "hop": 2 * s + g,            # read in, write out, read links
+        "hop_shifted": 3 * s + g,    # + read P0
+        "hop_shifted_gram": 3 * s + g,
+        "block_axpy": 3 * s,         # read x, read y, write y
+        "block_xpay": 3 * s,
+        "trisolve": 2 * s,
+        "gram_pair": 2 * s,
+        "gram_self": 1 * s,
+        "phaseB": 3 * s,             # Q -= T alpha (+ Gram of the new Q): read T, Q; write Q
+        "phaseC": (2 + 4 * S) * s,   # read Q, X_s, P_s; write Q, X_s, P_s
+    }
+    return V * table[name] if name in table else None
+
+
+def cpu_baseline(m, S, shifts, mass, budget_iters=8):
+    """Time the reference's own SBCGrQ (oracle/_ref, built from /root/reference in the build container)
+    or, if that is absent, this repository's CPU restatement, on one host core, at V = 16^4."""
+    import numpy as np
+    import oracle
+    dims = [16, 16, 16, 16]
+    V = 16 ** 4
+    O = oracle.Oracle()
+    cores = 1
+    if oracle.ref_available() and m in oracle.REF_SUPPORTED_M:
+        R = oracle.Reference(four_d=True)
+        U = O.fill_gauge(dims, 1)
+        B = O.fill_field(m, V, 2)
+        R.make_dirac_nd(dims, mass, U)
+        t_setup = R.sbcgrq(B, shifts, 0.0, 0.0, max_iterations=0)["seconds"]
+        t_total = R.sbcgrq(B, shifts, 0.0, 0.0, max_iterations=budget_iters)["seconds"]
+        kind = "reference"
+        what = "unmodified reference SBCGrQ + field primitives (oracle/_ref/libref4d.so) over the 4-D operator"
+    else:
+        dt, t_setup = O.bench_sbcgrq(m, dims, mass, shifts, budget_iters, seed=1)
+        t_total = dt + t_setup
+        kind = "port"
+        what = "CPU restatement oracle/oracle.hpp"
+    dt = max(t_total - t_setup, 1e-9)
+    return {"value": V * budget_iters / dt, "unit": "site-iter/s", "cores": cores, "kind": kind,
+            "sample": f"{what}; V=16^4, m={m}, {S} shifts, {budget_iters} fixed iterations (eps=0), "
+                      f"{dt:.2f} s on 1 of {os.cpu_count()} host cores",
+            "iterations_per_sec_at_sample": budget_iters / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--local-dims", type=int, nargs="+", default=[64, 64, 64, 64])
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--shifts", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the generic VALU kernels")
+    args = ap.parse_args()
+
+    import torch
+    import blockcg_amd as bc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    dist = None
+    comm = None
+    ndim = len(args.local_dims)
+    if world > 1:
+        import torch.distributed as dist
+        from blockcg_amd.comm import TorchDistComm, coords_of, grid_for
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=os.environ.get("BCG_BACKEND", "nccl"),
+                                device_id=torch.device("cuda", local_rank) if os.environ.get("BCG_BACKEND", "nccl") == "nccl" else None)
+        grid = grid_for(world, ndim)
+        coords = coords_of(rank, grid)
+        comm = TorchDistComm(local_rank)
+        gdims = [l * g for l, g in zip(args.local_dims, grid)]
+        ctx = bc.Context(gdims, device=local_rank, grid=grid, coords=coords, stream=comm.stream_ptr)
+        comm.attach(ctx)
+    else:
+        grid = [1] * ndim
+        gdims = list(args.local_dims)
+        ctx = bc.Context(gdims, device=local_rank)
+    if args.generic:
+        ctx.force_generic(True)
+
+    m, S = args.m, args.shifts
+    shifts = sorted(SHIFTS[:S])
+    D = bc.dirac_op(ctx, MASS, seed=1)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=2)
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0, consume_B=True)
+    st.iterate(args.warmup)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    ctx.profiling(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    st.iterate(args.steps)          # EXACTLY K iterations; iterate() synchronizes the stream before returning
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    residual = st.residual
+    st.end()
+    if comm is not None and comm.error is not None:
+        raise comm.error
+
+    if rank == 0:
+        Vg = 1
+        for d in gdims:
+            Vg *= d
+        K = args.steps
+        its = K / dt
+        bytes_iter_total = ctx.bytes_per_iteration(m, S) * world
+        hbm_gbps = bytes_iter_total * its / 1e9
+        # dominant kernel of the timed region, from the HIP-event timings taken inside it
+        roof = None
+        if prof:
+            name = max(prof, key=lambda k: prof[k]["ms"])
+            avg_ms = prof[name]["ms"] / prof[name]["count"]
+            kb = kernel_bytes(name, ctx.V, m, S, ndim)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name, {}).get("bytes_per_launch")
+            if kb is not None:
+                ach = kb / (avg_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                        "launches": prof[name]["count"], "algorithmic_bytes_per_launch": kb}
+        out = {
+            "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
+            "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
+                                   f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)",
+                       "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts},
+            "iterations_per_sec": its,
+            "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,
+            "hbm_roofline_frac_whole_iteration": hbm_gbps / world / HBM_PEAK_GBPS,
+            "residual_after_timed_steps": residual,
+            "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(m, S, shifts, MASS)
+                out["gpu_over_cpu_site_iter_rate"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # the bench line must still print
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

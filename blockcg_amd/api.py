@@ -1,0 +1,315 @@
+"""Python mirror of the reference's header-level interface over the C ABI.
+
+Names and argument meaning follow the reference so that parity tests read like its own tests
+(test/solvers.cpp): block_fermion_field(V-or-context, N_rhs), dirac_op(context, mass),
+SBCGrQ(X, B, D, sigma, eps, eps_shifts, max_iterations) -> number of operator applications.
+Host arrays are numpy complex128 in the reference's layout: field [V, m, 3]; gauge
+[V, ndim, 3, 3] with [.., k, r] = U(r, k); m x m matrices as ordinary (row, col) numpy arrays.
+"""
+import ctypes
+import json
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_dbl_p
+
+SUPPORTED_WIDTHS = (1, 2, 3, 4, 6, 8, 12, 16, 32)
+
+_STATUS = {1: "BCG_ERR_INVALID", 2: "BCG_ERR_UNSUPPORTED", 3: "BCG_ERR_HIP", 4: "BCG_ERR_NO_DEVICE", 5: "BCG_ERR_COMM",
+           6: "BCG_ERR_NUMERIC"}
+
+
+class BlockCGError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dbl_p)
+
+
+def _mat_in(M, m):
+    M = np.asarray(M, dtype=np.complex128)
+    if M.shape != (m, m):
+        raise ValueError(f"expected a {m}x{m} matrix")
+    return np.ascontiguousarray(M.T)  # column-major buffer
+
+
+def _ivec(v, n=4, fill=1):
+    v = list(v) + [fill] * (n - len(v))
+    return (ctypes.c_int * n)(*v)
+
+
+class Context:
+    """One GPU = one rank of the process grid over a periodic lattice of up to 4 dimensions."""
+
+    def __init__(self, dims, device=0, grid=None, coords=None, stream=None):
+        self.lib = _lib.load()
+        self.dims = [int(d) for d in dims]
+        self.ndim = len(self.dims)
+        self.grid = [int(g) for g in grid] if grid is not None else [1] * self.ndim
+        self.coords = [int(x) for x in coords] if coords is not None else [0] * self.ndim
+        h = ctypes.c_void_p()
+        rc = self.lib.bcg_context_create(ctypes.byref(h), device, stream, self.ndim, _ivec(self.dims), _ivec(self.grid),
+                                         _ivec(self.coords, fill=0))
+        if rc != 0:
+            raise BlockCGError(rc, self.lib.bcg_last_error(None).decode())
+        self.h = h
+        self._comm_keepalive = None
+        ld = (ctypes.c_int * 4)()
+        og = (ctypes.c_int * 4)()
+        self.lib.bcg_local_dims(self.h, ld, og)
+        self.local_dims = list(ld)[:self.ndim]
+        self.origin = list(og)[:self.ndim]
+        self.V = int(self.lib.bcg_local_volume(self.h))
+
+    def check(self, rc):
+        if rc != 0:
+            raise BlockCGError(rc, self.lib.bcg_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bcg_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(self.lib.bcg_synchronize(self.h))
+
+    def profiling(self, enable=True):
+        self.check(self.lib.bcg_profiling(self.h, 1 if enable else 0))
+
+    def profile_reset(self):
+        self.check(self.lib.bcg_profile_reset(self.h))
+
+    def profile(self):
+        return json.loads(self.lib.bcg_profile_json(self.h).decode())
+
+    def force_generic(self, enable=True):
+        self.check(self.lib.bcg_force_generic(self.h, 1 if enable else 0))
+
+    def halo_buffers(self):
+        s = ctypes.c_void_p()
+        r = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        self.check(self.lib.bcg_halo_buffers(self.h, ctypes.byref(s), ctypes.byref(r), ctypes.byref(n)))
+        return s.value, r.value, n.value
+
+    def set_comm(self, comm_struct, keepalive):
+        self._comm_keepalive = (comm_struct, keepalive)
+        self.check(self.lib.bcg_context_set_comm(self.h, ctypes.byref(comm_struct)))
+
+    def bytes_per_iteration(self, m, n_shifts):
+        return float(self.lib.bcg_sbcgrq_bytes_per_iteration(self.h, m, n_shifts))
+
+
+class block_fermion_field:
+    """Device block field (inc/fields.hpp:25-147).  `N_rhs` is the reference's template parameter."""
+
+    def __init__(self, ctx, N_rhs, host=None):
+        self.ctx = ctx
+        self.N_rhs = int(N_rhs)
+        self.V = ctx.V
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.bcg_field_create(ctx.h, self.N_rhs, ctypes.byref(h)))
+        self.h = h
+        if host is not None:
+            self.upload(host)
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.bcg_field_destroy(self.h)
+            self.h = None
+        except Exception:
+            pass
+
+    # host <-> device
+    def upload(self, host):
+        a = np.ascontiguousarray(host, dtype=np.complex128)
+        if a.shape != (self.V, self.N_rhs, 3):
+            raise ValueError(f"expected host array of shape {(self.V, self.N_rhs, 3)}, got {a.shape}")
+        self.ctx.check(self.ctx.lib.bcg_field_upload(self.h, _dp(a)))
+        return self
+
+    def download(self):
+        a = np.empty((self.V, self.N_rhs, 3), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.bcg_field_download(self.h, _dp(a)))
+        return a
+
+    def copy(self):
+        f = block_fermion_field(self.ctx, self.N_rhs)
+        self.ctx.check(self.ctx.lib.bcg_field_copy(f.h, self.h))
+        return f
+
+    def setZero(self):
+        self.ctx.check(self.ctx.lib.bcg_field_set_zero(self.h))
+        return self
+
+    def setRandom(self, seed=1):
+        self.ctx.check(self.ctx.lib.bcg_field_fill_random(self.h, seed))
+        return self
+
+    def __iadd__(self, rhs):
+        self.ctx.check(self.ctx.lib.bcg_field_add_assign(self.h, rhs.h))
+        return self
+
+    def __isub__(self, rhs):
+        self.ctx.check(self.ctx.lib.bcg_field_sub_assign(self.h, rhs.h))
+        return self
+
+    def add(self, rhs, rhs_multiplier):
+        """this += rhs * rhs_multiplier  (scalar or m x m)  inc/fields.hpp:70-77"""
+        if np.isscalar(rhs_multiplier):
+            self.ctx.check(self.ctx.lib.bcg_field_add_scalar(self.h, rhs.h, float(rhs_multiplier)))
+        else:
+            M = _mat_in(rhs_multiplier, self.N_rhs)
+            self.ctx.check(self.ctx.lib.bcg_field_add_matrix(self.h, rhs.h, _dp(M)))
+        return self
+
+    def rescale_add(self, lhs_multiplier, rhs, rhs_multiplier):
+        """this = this * lhs_multiplier + rhs * rhs_multiplier  inc/fields.hpp:79-90"""
+        if np.isscalar(lhs_multiplier):
+            self.ctx.check(self.ctx.lib.bcg_field_rescale_add_scalar(self.h, float(lhs_multiplier), rhs.h,
+                                                                     float(rhs_multiplier)))
+        else:
+            M = _mat_in(lhs_multiplier, self.N_rhs)
+            self.ctx.check(self.ctx.lib.bcg_field_rescale_add_matrix(self.h, _dp(M), rhs.h, float(rhs_multiplier)))
+        return self
+
+    def hermitian_dot(self, rhs):
+        m = self.N_rhs
+        out = np.empty((m, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.bcg_field_hermitian_dot(self.h, rhs.h, _dp(out)))
+        return np.ascontiguousarray(out.T)
+
+    def real_dot(self, rhs):
+        out = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.bcg_field_real_dot(self.h, rhs.h, ctypes.byref(out)))
+        return out.value
+
+    def multiply_upper_triangular_inverse_RHS(self, R):
+        M = _mat_in(R, self.N_rhs)
+        self.ctx.check(self.ctx.lib.bcg_field_tri_solve_rhs(self.h, _dp(M)))
+        return self
+
+    def thinQR(self):
+        """In place; returns R (the reference fills its argument, inc/fields.hpp:140-146)."""
+        m = self.N_rhs
+        out = np.empty((m, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.bcg_field_thin_qr(self.h, _dp(out)))
+        return np.ascontiguousarray(out.T)
+
+
+class dirac_op:
+    """inc/dirac_op.hpp:8-44 on a device lattice: public V, mass; op(lhs, rhs)."""
+
+    def __init__(self, ctx, mass=0.1, U=None, seed=None):
+        self.ctx = ctx
+        self.V = ctx.V
+        self.mass = float(mass)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.bcg_gauge_create(ctx.h, ctypes.byref(h)))
+        self.h = h
+        if U is not None:
+            self.set_links(U)
+        elif seed is not None:
+            ctx.check(ctx.lib.bcg_gauge_fill_random(self.h, seed))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.bcg_gauge_destroy(self.h)
+            self.h = None
+        except Exception:
+            pass
+
+    def set_links(self, U):
+        a = np.ascontiguousarray(U, dtype=np.complex128)
+        if a.shape != (self.V, self.ctx.ndim, 3, 3):
+            raise ValueError(f"expected links of shape {(self.V, self.ctx.ndim, 3, 3)}, got {a.shape}")
+        self.ctx.check(self.ctx.lib.bcg_gauge_upload(self.h, _dp(a)))
+
+    def op(self, lhs, rhs):
+        self.ctx.check(self.ctx.lib.bcg_dirac_apply(self.ctx.h, self.h, self.mass, lhs.h, rhs.h))
+
+    def D(self, lhs, rhs):
+        """The reference's private hop (inc/dirac_op.hpp:14-21), exposed for tests."""
+        self.ctx.check(self.ctx.lib.bcg_dirac_hop(self.ctx.h, self.h, lhs.h, rhs.h))
+
+
+def SBCGrQ(X, B, D, sigma, eps=1.e-15, eps_shifts=1.e-15, max_iterations=1000000, trace_limit=0, consume_B=False,
+           return_info=False):
+    """inc/block_solvers.hpp:91-185.  X: list of fields (overwritten); returns operator applications."""
+    ctx = B.ctx
+    S = len(X)
+    if len(sigma) != S:
+        raise ValueError("number of shifts does not match number of solution vectors")  # :97-98
+    m = B.N_rhs
+    sig = np.ascontiguousarray(sigma, dtype=np.float64)
+    Xh = (ctypes.c_void_p * S)(*[x.h for x in X])
+    it = ctypes.c_int(0)
+    res = ctypes.c_double(0.0)
+    tr = None
+    tr_p = None
+    if trace_limit > 0:
+        mats = np.zeros((trace_limit, 3 + 2 * S, m, m), dtype=np.complex128)
+        rr = np.zeros((trace_limit, 1 + S), dtype=np.float64)
+        tr = _lib.bcg_sbcgrq_trace(trace_limit, 0, _dp(mats), _dp(rr))
+        tr_p = ctypes.byref(tr)
+    ctx.check(ctx.lib.bcg_sbcgrq_solve(ctx.h, D.h, D.mass, Xh, B.h, S, _dp(sig), eps, eps_shifts, int(max_iterations),
+                                       1 if consume_B else 0, ctypes.byref(it), ctypes.byref(res), tr_p))
+    if not return_info:
+        return it.value
+    info = dict(iterations=it.value, residual=res.value, trace=None)
+    if tr is not None:
+        n = tr.recorded
+        mt = np.ascontiguousarray(np.swapaxes(mats[:n], -1, -2))
+        info["trace"] = dict(alpha=mt[:, 0], rho=mt[:, 1], delta=mt[:, 2], alpha_s=mt[:, 3:3 + S],
+                             beta_s=mt[:, 3 + S:3 + 2 * S], residual=rr[:n, 0], residual_shift=rr[:n, 1:])
+    return info
+
+
+class SBCGrQState:
+    """The solver as a resumable state machine (bcg_sbcgrq_begin / iterate / end): lets bench.py run
+    W warm-up iterations, then time exactly K iterations of the hot loop."""
+
+    def __init__(self, X, B, D, sigma, eps=0.0, eps_shifts=0.0, consume_B=False):
+        self.ctx = B.ctx
+        self._keep = (X, B, D)
+        S = len(X)
+        if len(sigma) != S:
+            raise ValueError("number of shifts does not match number of solution vectors")
+        sig = np.ascontiguousarray(sigma, dtype=np.float64)
+        Xh = (ctypes.c_void_p * S)(*[x.h for x in X])
+        st = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.bcg_sbcgrq_begin(self.ctx.h, D.h, D.mass, Xh, B.h, S, _dp(sig), eps, eps_shifts,
+                                                     1 if consume_B else 0, ctypes.byref(st)))
+        self.h = st
+        self.iterations = 0
+        self.residual = 1.0
+
+    def iterate(self, n):
+        it = ctypes.c_int(0)
+        res = ctypes.c_double(0.0)
+        self.ctx.check(self.ctx.lib.bcg_sbcgrq_iterate(self.h, int(n), ctypes.byref(it), ctypes.byref(res), None))
+        self.iterations, self.residual = it.value, res.value
+        return it.value
+
+    def end(self):
+        if self.h:
+            self.ctx.lib.bcg_sbcgrq_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass

@@ -1,0 +1,925 @@
+// Implementation of include/blockcg_hip.h: context, fields, operator and the SBCGrQ driver.
+//
+// Host side of the hot path: this file holds the reference's control flow
+// (inc/block_solvers.hpp:91-185) and its m x m coefficient algebra; every loop over lattice sites
+// is a HIP kernel (kernels_generic.hip, kernels_mfma.hip).  There is no CPU fallback: without a
+// gfx950 device bcg_context_create fails with BCG_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "context.hpp"
+
+using bcg::CMat;
+using bcg::cd;
+
+namespace {
+
+std::string g_create_error;
+
+#define BCG_FAIL(ctx, code, msg) \
+  do {                           \
+    (ctx)->err = (msg);          \
+    return (code);               \
+  } while (0)
+
+#define HIP_TRY(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return BCG_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+#define BCG_TRY(call)            \
+  do {                           \
+    int rc_ = (call);            \
+    if (rc_ != BCG_OK) return rc_; \
+  } while (0)
+
+// ---- profiling: HIP events on the context's stream around each kernel class ------------------
+struct ProfScope {
+  bcg_context* c;
+  bcg::ProfEntry* e = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(bcg_context* ctx, const char* name) : c(ctx) {
+    if (!c->profiling) return;
+    e = &c->prof[name];
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~ProfScope() {
+    if (!e) return;
+    (void)hipEventRecord(b, c->stream);
+    e->pending.emplace_back(a, b);
+  }
+  hipEvent_t take() {
+    if (!c->event_pool.empty()) {
+      hipEvent_t ev = c->event_pool.back();
+      c->event_pool.pop_back();
+      return ev;
+    }
+    hipEvent_t ev;
+    (void)hipEventCreate(&ev);
+    return ev;
+  }
+};
+
+void resolve_profile(bcg_context* c) {
+  for (auto& kv : c->prof) {
+    for (auto& pr : kv.second.pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        kv.second.ms += ms;
+        kv.second.count += 1;
+      }
+      c->event_pool.push_back(pr.first);
+      c->event_pool.push_back(pr.second);
+    }
+    kv.second.pending.clear();
+  }
+}
+
+int stream_sync(bcg_context* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->mat_in_flight = 0;
+  if (c->profiling) resolve_profile(c);
+  return BCG_OK;
+}
+
+int check_launch(bcg_context* c, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return BCG_ERR_HIP;
+  }
+  return BCG_OK;
+}
+
+// ---- scratch management -----------------------------------------------------------------------
+int ensure_halo(bcg_context* c, size_t bytes) {
+  if (bytes <= c->halo_bytes) return BCG_OK;
+  BCG_TRY(stream_sync(c));
+  if (c->halo_send) (void)hipFree(c->halo_send);
+  if (c->halo_recv) (void)hipFree(c->halo_recv);
+  c->halo_send = c->halo_recv = nullptr;
+  c->halo_bytes = 0;
+  HIP_TRY(c, hipMalloc(&c->halo_send, bytes));
+  HIP_TRY(c, hipMalloc(&c->halo_recv, bytes));
+  c->halo_bytes = bytes;
+  return BCG_OK;
+}
+
+constexpr int kMaxGramBlocks = 1024;
+constexpr size_t kMatSlotBytes = 32 * 32 * sizeof(double2);
+constexpr int kMatSlots = 96;
+
+int ensure_scratch(bcg_context* c) {
+  if (!c->partials) {
+    c->partials_bytes = static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2);
+    HIP_TRY(c, hipMalloc(&c->partials, c->partials_bytes));
+  }
+  if (!c->dev_mats) {
+    c->mat_slot_bytes = kMatSlotBytes;
+    c->mat_slots = kMatSlots;
+    HIP_TRY(c, hipMalloc(&c->dev_mats, kMatSlotBytes * kMatSlots));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_mats), kMatSlotBytes * kMatSlots, hipHostMallocDefault));
+  }
+  if (!c->dev_gram) {
+    HIP_TRY(c, hipMalloc(&c->dev_gram, kMatSlotBytes));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_gram), kMatSlotBytes, hipHostMallocDefault));
+  }
+  return BCG_OK;
+}
+
+// Copy n coefficient matrices (m x m each) to consecutive device slots; returns the device pointer
+// of the first.  Slots are recycled only after a stream synchronization.
+int upload_mats(bcg_context* c, int m, const CMat* const* mats, int n, const double2** dev_out) {
+  BCG_TRY(ensure_scratch(c));
+  const size_t each = static_cast<size_t>(m) * m * sizeof(double2);
+  const size_t total = each * n;
+  const int need = static_cast<int>((total + c->mat_slot_bytes - 1) / c->mat_slot_bytes);
+  if (need > c->mat_slots) BCG_FAIL(c, BCG_ERR_INVALID, "too many coefficient matrices in one upload");
+  if (c->mat_next + need > c->mat_slots) {
+    c->mat_in_flight += c->mat_slots - c->mat_next;
+    c->mat_next = 0;
+  }
+  if (c->mat_in_flight + need > c->mat_slots) BCG_TRY(stream_sync(c));
+  char* hp = reinterpret_cast<char*>(c->pin_mats) + c->mat_next * c->mat_slot_bytes;
+  char* dp = reinterpret_cast<char*>(c->dev_mats) + c->mat_next * c->mat_slot_bytes;
+  for (int k = 0; k < n; ++k) std::memcpy(hp + k * each, mats[k]->data(), each);
+  HIP_TRY(c, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream));
+  c->mat_next += need;
+  c->mat_in_flight += need;
+  *dev_out = reinterpret_cast<const double2*>(dp);
+  return BCG_OK;
+}
+int upload_mat(bcg_context* c, const CMat& M, const double2** dev_out) {
+  const CMat* p = &M;
+  return upload_mats(c, M.dim(), &p, 1, dev_out);
+}
+
+int ensure_staging(bcg_context* c, size_t bytes) {
+  if (bytes <= c->staging_bytes) return BCG_OK;
+  if (c->staging) (void)hipFree(c->staging);
+  c->staging = nullptr;
+  c->staging_bytes = 0;
+  HIP_TRY(c, hipMalloc(&c->staging, bytes));
+  c->staging_bytes = bytes;
+  return BCG_OK;
+}
+
+inline int64_t rows_of(const bcg_context* c) { return c->lat.V * 3; }
+inline size_t field_bytes(const bcg_context* c, int m) { return static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2); }
+
+// ---- halo exchange -----------------------------------------------------------------------------
+int rank_of(const bcg_context* c, const int* xyz) {
+  // rank = lexicographic index of grid coordinates, direction 0 fastest
+  int r = 0, st = 1;
+  for (int mu = 0; mu < 4; ++mu) {
+    r += xyz[mu] * st;
+    st *= c->grid[mu];
+  }
+  return r;
+}
+
+// Post the face messages for rows of `row_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).
+int exchange_faces(bcg_context* c, size_t site_bytes) {
+  if (!c->have_comm || !c->comm.halo_exchange) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
+  int peer_s[8], peer_r[8];
+  size_t off_s[8], off_r[8], nb[8];
+  int n = 0;
+  for (int mu = 0; mu < c->ndim; ++mu) {
+    if (!c->lat.split[mu]) continue;
+    int xm[4], xp[4];
+    for (int nu = 0; nu < 4; ++nu) xm[nu] = xp[nu] = c->coords[nu];
+    xm[mu] = (c->coords[mu] - 1 + c->grid[mu]) % c->grid[mu];
+    xp[mu] = (c->coords[mu] + 1) % c->grid[mu];
+    const int rm = rank_of(c, xm), rp = rank_of(c, xp);
+    const size_t face = static_cast<size_t>(c->lat.face_sites[mu]) * site_bytes;
+    const size_t base = static_cast<size_t>(c->lat.ghost_off[mu][0]) * site_bytes;
+    // low face -> minus neighbour (its plus ghost); my plus ghost <- plus neighbour's low face
+    peer_s[n] = rm; peer_r[n] = rp; off_s[n] = base; off_r[n] = base + face; nb[n] = face; ++n;
+    // high face -> plus neighbour (its minus ghost); my minus ghost <- minus neighbour's high face
+    peer_s[n] = rp; peer_r[n] = rm; off_s[n] = base + face; off_r[n] = base; nb[n] = face; ++n;
+  }
+  if (c->comm.halo_exchange(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0)
+    BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
+  return BCG_OK;
+}
+
+int halo_field(bcg_context* c, const bcg_field* f) {
+  if (!c->distributed) return BCG_OK;
+  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
+  BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
+  {
+    ProfScope ps(c, "pack_faces");
+    bcg::launch_pack_faces(c->stream, f->m, c->lat, f->d, c->halo_send);
+  }
+  BCG_TRY(check_launch(c, "pack_faces"));
+  ProfScope ps(c, "halo_exchange");
+  return exchange_faces(c, site_bytes);
+}
+
+int halo_gauge(bcg_context* c, bcg_gauge* g) {
+  if (!c->distributed || g->ghost_valid) return BCG_OK;
+  const size_t site_bytes = 9 * sizeof(double2);
+  BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
+  bcg::launch_pack_gauge_faces(c->stream, c->lat, g->U, c->halo_send);
+  BCG_TRY(check_launch(c, "pack_gauge_faces"));
+  BCG_TRY(exchange_faces(c, site_bytes));
+  HIP_TRY(c, hipMemcpyAsync(g->Ughost, c->halo_recv, static_cast<size_t>(c->ghost_sites) * site_bytes,
+                            hipMemcpyDeviceToDevice, c->stream));
+  BCG_TRY(stream_sync(c));
+  g->ghost_valid = true;
+  return BCG_OK;
+}
+
+// ---- building blocks ---------------------------------------------------------------------------
+bool same_shape(const bcg_field* a, const bcg_field* b) { return a && b && a->ctx == b->ctx && a->m == b->m; }
+
+int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
+        double c0) {
+  BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+  BCG_TRY(halo_field(c, in));
+  {
+    ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
+    bcg::launch_hop_generic(c->stream, in->m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+                            p ? p->d : nullptr, c0);
+  }
+  return check_launch(c, "hop");
+}
+
+// G = a^dagger b summed over all ranks, Hermitian-mirrored exactly as inc/fields.hpp:115-120.
+int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool mirror = true) {
+  BCG_TRY(ensure_scratch(c));
+  const int m = a->m;
+  int nblocks;
+  {
+    ProfScope ps(c, a == b ? "gram_self" : "gram_pair");
+    nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(c), a->d, b->d, c->partials, kMaxGramBlocks);
+  }
+  BCG_TRY(check_launch(c, "gram"));
+  {
+    ProfScope ps(c, "reduce_partials");
+    bcg::launch_reduce_partials(c->stream, m * m, nblocks, c->partials, c->dev_gram);
+  }
+  BCG_TRY(check_launch(c, "reduce_partials"));
+  if (c->distributed) {
+    if (!c->have_comm || !c->comm.allreduce_sum) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
+    ProfScope ps(c, "allreduce");
+    if (c->comm.allreduce_sum(c->comm.user, c->dev_gram, static_cast<size_t>(2) * m * m) != 0)
+      BCG_FAIL(c, BCG_ERR_COMM, "allreduce_sum callback failed");
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->pin_gram, c->dev_gram, static_cast<size_t>(m) * m * sizeof(double2),
+                            hipMemcpyDeviceToHost, c->stream));
+  BCG_TRY(stream_sync(c));
+  G = CMat(m, c->pin_gram);
+  if (mirror)
+    for (int i = 1; i < m; ++i)
+      for (int j = 0; j < i; ++j) G(j, i) = std::conj(G(i, j));
+  return BCG_OK;
+}
+
+int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double b, bcg::RmulMode mode, const char* name) {
+  const double2* Md;
+  BCG_TRY(upload_mat(c, M, &Md));
+  {
+    ProfScope ps(c, name);
+    bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
+  }
+  return check_launch(c, name);
+}
+
+int trisolve(bcg_context* c, bcg_field* y, const CMat& R) {
+  const double2* Rd;
+  BCG_TRY(upload_mat(c, R, &Rd));
+  {
+    ProfScope ps(c, "trisolve");
+    bcg::launch_trisolve_generic(c->stream, y->m, rows_of(c), y->d, Rd);
+  }
+  return check_launch(c, "trisolve");
+}
+
+int axpby(bcg_context* c, bcg_field* y, double a, const bcg_field* x, double b, const char* name) {
+  {
+    ProfScope ps(c, name);
+    bcg::launch_axpby(c->stream, y->d, a, x->d, b, rows_of(c) * y->m);
+  }
+  return check_launch(c, name);
+}
+
+int get_tmp(bcg_context* c, int m, bcg_field** out) {
+  auto it = c->tmp_field.find(m);
+  if (it != c->tmp_field.end()) {
+    *out = it->second;
+    return BCG_OK;
+  }
+  bcg_field* f = nullptr;
+  BCG_TRY(bcg_field_create(c, m, &f));
+  c->tmp_field[m] = f;
+  *out = f;
+  return BCG_OK;
+}
+
+// T = (mass^2 + sigma0) P - D(D(P))   [op + add(P, sigma0), inc/block_solvers.hpp:134-136]
+int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P) {
+  bcg_field* tmp;
+  BCG_TRY(get_tmp(c, P->m, &tmp));
+  BCG_TRY(hop(c, g, tmp, P, bcg::HOP_PLAIN, nullptr, 0.0));
+  return hop(c, g, T, tmp, bcg::HOP_SHIFTED, P, mass * mass + sigma0);
+}
+
+// thinQR (inc/fields.hpp:140-146)
+int thin_qr(bcg_context* c, bcg_field* y, CMat& R) {
+  CMat G;
+  BCG_TRY(gram(c, y, y, G));
+  if (!G.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not finite");
+  if (!bcg::cholesky_upper(G, R)) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not positive definite");
+  return trisolve(c, y, R);
+}
+
+double max_ratio(const std::vector<double>& num, const std::vector<double>& den) {
+  double r = 0.0;
+  for (size_t i = 0; i < num.size(); ++i) r = std::max(r, num[i] / den[i]);
+  return r;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* bcg_last_error(const bcg_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, const int* global_dims, const int* grid,
+                       const int* coords) {
+  if (!out || !global_dims || ndim < 1 || ndim > 4) {
+    g_create_error = "bcg_context_create: bad arguments";
+    return BCG_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_create_error = "bcg_context_create: no usable HIP device (this library has no CPU fallback)";
+    return BCG_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("bcg_context_create: device is not gfx950 (MI355X): ") + prop.gcnArchName;
+    return BCG_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_create_error = "bcg_context_create: hipSetDevice failed";
+    return BCG_ERR_HIP;
+  }
+  bcg_context* c = new bcg_context();
+  c->device = device;
+  c->ndim = ndim;
+  int64_t V = 1;
+  int64_t ghost = 0;
+  for (int mu = 0; mu < 4; ++mu) {
+    c->gdims[mu] = mu < ndim ? global_dims[mu] : 1;
+    c->grid[mu] = (mu < ndim && grid) ? grid[mu] : 1;
+    c->coords[mu] = (mu < ndim && coords) ? coords[mu] : 0;
+    if (c->gdims[mu] < 1 || c->grid[mu] < 1 || c->gdims[mu] % c->grid[mu] != 0 || c->coords[mu] < 0 ||
+        c->coords[mu] >= c->grid[mu]) {
+      g_create_error = "bcg_context_create: lattice extents must be positive multiples of the process grid";
+      delete c;
+      return BCG_ERR_INVALID;
+    }
+    c->lat.L[mu] = c->gdims[mu] / c->grid[mu];
+    c->lat.origin[mu] = c->coords[mu] * c->lat.L[mu];
+    c->lat.split[mu] = c->grid[mu] > 1 ? 1 : 0;
+    c->lat.stride[mu] = V;
+    V *= c->lat.L[mu];
+    if (c->lat.split[mu]) c->distributed = true;
+  }
+  c->lat.ndim = ndim;
+  c->lat.V = V;
+  for (int mu = 0; mu < 4; ++mu) {
+    c->lat.face_sites[mu] = V / c->lat.L[mu];
+    c->lat.ghost_off[mu][0] = c->lat.ghost_off[mu][1] = 0;
+    if (c->lat.split[mu]) {
+      c->lat.ghost_off[mu][0] = ghost;
+      c->lat.ghost_off[mu][1] = ghost + c->lat.face_sites[mu];
+      ghost += 2 * c->lat.face_sites[mu];
+    }
+  }
+  c->ghost_sites = ghost;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      g_create_error = "bcg_context_create: hipStreamCreate failed";
+      delete c;
+      return BCG_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return BCG_OK;
+}
+
+int bcg_context_destroy(bcg_context* c) {
+  if (!c) return BCG_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->tmp_field) {
+    (void)hipFree(kv.second->d);
+    delete kv.second;
+  }
+  if (c->halo_send) (void)hipFree(c->halo_send);
+  if (c->halo_recv) (void)hipFree(c->halo_recv);
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->dev_mats) (void)hipFree(c->dev_mats);
+  if (c->pin_mats) (void)hipHostFree(c->pin_mats);
+  if (c->dev_gram) (void)hipFree(c->dev_gram);
+  if (c->pin_gram) (void)hipHostFree(c->pin_gram);
+  if (c->staging) (void)hipFree(c->staging);
+  for (auto& kv : c->prof)
+    for (auto& pr : kv.second.pending) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return BCG_OK;
+}
+
+int bcg_context_set_comm(bcg_context* c, const bcg_comm* comm) {
+  if (!c) return BCG_ERR_INVALID;
+  if (comm) {
+    c->comm = *comm;
+    c->have_comm = true;
+  } else {
+    c->have_comm = false;
+  }
+  return BCG_OK;
+}
+
+int64_t bcg_local_volume(const bcg_context* c) { return c ? c->lat.V : -1; }
+
+int bcg_local_dims(const bcg_context* c, int* dims4, int* origin4) {
+  if (!c) return BCG_ERR_INVALID;
+  for (int mu = 0; mu < 4; ++mu) {
+    if (dims4) dims4[mu] = c->lat.L[mu];
+    if (origin4) origin4[mu] = c->lat.origin[mu];
+  }
+  return BCG_OK;
+}
+
+int bcg_halo_buffers(bcg_context* c, void** send, void** recv, size_t* bytes_each) {
+  if (!c) return BCG_ERR_INVALID;
+  if (send) *send = c->halo_send;
+  if (recv) *recv = c->halo_recv;
+  if (bytes_each) *bytes_each = c->halo_bytes;
+  return BCG_OK;
+}
+
+int bcg_synchronize(bcg_context* c) {
+  if (!c) return BCG_ERR_INVALID;
+  return stream_sync(c);
+}
+
+int bcg_profiling(bcg_context* c, int enable) {
+  if (!c) return BCG_ERR_INVALID;
+  BCG_TRY(stream_sync(c));
+  c->profiling = enable != 0;
+  return BCG_OK;
+}
+
+int bcg_profile_reset(bcg_context* c) {
+  if (!c) return BCG_ERR_INVALID;
+  BCG_TRY(stream_sync(c));
+  for (auto& kv : c->prof) {
+    kv.second.ms = 0;
+    kv.second.count = 0;
+  }
+  return BCG_OK;
+}
+
+const char* bcg_profile_json(bcg_context* c) {
+  if (!c) return "{}";
+  (void)stream_sync(c);
+  std::ostringstream os;
+  os << "{";
+  bool first = true;
+  for (auto& kv : c->prof) {
+    if (kv.second.count == 0) continue;
+    if (!first) os << ", ";
+    first = false;
+    os << "\"" << kv.first << "\": {\"ms\": " << kv.second.ms << ", \"count\": " << kv.second.count << "}";
+  }
+  os << "}";
+  c->prof_json = os.str();
+  return c->prof_json.c_str();
+}
+
+int bcg_force_generic(bcg_context* c, int enable) {
+  if (!c) return BCG_ERR_INVALID;
+  c->force_generic = enable != 0;
+  return BCG_OK;
+}
+
+// ---- fields ------------------------------------------------------------------------------------
+int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
+  if (!c || !out) return BCG_ERR_INVALID;
+  if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
+  bcg_field* f = new bcg_field{c, m, nullptr};
+  hipError_t e = hipMalloc(&f->d, field_bytes(c, m));
+  if (e != hipSuccess) {
+    delete f;
+    c->err = std::string("bcg_field_create: hipMalloc: ") + hipGetErrorString(e);
+    return BCG_ERR_HIP;
+  }
+  *out = f;
+  return BCG_OK;
+}
+
+int bcg_field_destroy(bcg_field* f) {
+  if (!f) return BCG_OK;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  (void)hipFree(f->d);
+  delete f;
+  return BCG_OK;
+}
+
+int bcg_field_width(const bcg_field* f) { return f ? f->m : -1; }
+
+int bcg_field_upload(bcg_field* f, const double* host) {
+  if (!f || !host) return BCG_ERR_INVALID;
+  bcg_context* c = f->ctx;
+  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
+  const int64_t chunk = std::min<int64_t>(c->lat.V, 1 << 18);
+  BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
+  for (int64_t s0 = 0; s0 < c->lat.V; s0 += chunk) {
+    const int64_t n = std::min<int64_t>(chunk, c->lat.V - s0);
+    HIP_TRY(c, hipMemcpyAsync(c->staging, reinterpret_cast<const char*>(host) + s0 * site_bytes, n * site_bytes,
+                              hipMemcpyHostToDevice, c->stream));
+    bcg::launch_host_to_dev(c->stream, f->m, c->staging, f->d + s0 * 3 * f->m, n);
+    BCG_TRY(check_launch(c, "host_to_dev"));
+    BCG_TRY(stream_sync(c));
+  }
+  return BCG_OK;
+}
+
+int bcg_field_download(const bcg_field* f, double* host) {
+  if (!f || !host) return BCG_ERR_INVALID;
+  bcg_context* c = f->ctx;
+  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
+  const int64_t chunk = std::min<int64_t>(c->lat.V, 1 << 18);
+  BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
+  for (int64_t s0 = 0; s0 < c->lat.V; s0 += chunk) {
+    const int64_t n = std::min<int64_t>(chunk, c->lat.V - s0);
+    bcg::launch_dev_to_host(c->stream, f->m, f->d + s0 * 3 * f->m, c->staging, n);
+    BCG_TRY(check_launch(c, "dev_to_host"));
+    HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char*>(host) + s0 * site_bytes, c->staging, n * site_bytes,
+                              hipMemcpyDeviceToHost, c->stream));
+    BCG_TRY(stream_sync(c));
+  }
+  return BCG_OK;
+}
+
+int bcg_field_copy(bcg_field* dst, const bcg_field* src) {
+  if (!same_shape(dst, src)) return BCG_ERR_INVALID;
+  bcg_context* c = dst->ctx;
+  ProfScope ps(c, "copy");
+  HIP_TRY(c, hipMemcpyAsync(dst->d, src->d, field_bytes(c, dst->m), hipMemcpyDeviceToDevice, c->stream));
+  return BCG_OK;
+}
+
+int bcg_field_set_zero(bcg_field* f) {
+  if (!f) return BCG_ERR_INVALID;
+  bcg_context* c = f->ctx;
+  ProfScope ps(c, "set_zero");
+  HIP_TRY(c, hipMemsetAsync(f->d, 0, field_bytes(c, f->m), c->stream));
+  return BCG_OK;
+}
+
+int bcg_field_fill_random(bcg_field* f, uint64_t seed) {
+  if (!f) return BCG_ERR_INVALID;
+  bcg_context* c = f->ctx;
+  bcg::launch_fill_field(c->stream, f->m, c->lat, c->gdims, f->d, seed);
+  return check_launch(c, "fill_field");
+}
+
+int bcg_field_add_assign(bcg_field* y, const bcg_field* x) {
+  if (!same_shape(y, x)) return BCG_ERR_INVALID;
+  return axpby(y->ctx, y, 1.0, x, 1.0, "axpby");
+}
+int bcg_field_sub_assign(bcg_field* y, const bcg_field* x) {
+  if (!same_shape(y, x)) return BCG_ERR_INVALID;
+  return axpby(y->ctx, y, 1.0, x, -1.0, "axpby");
+}
+int bcg_field_add_scalar(bcg_field* y, const bcg_field* x, double a) {
+  if (!same_shape(y, x)) return BCG_ERR_INVALID;
+  return axpby(y->ctx, y, 1.0, x, a, "axpby");
+}
+int bcg_field_rescale_add_scalar(bcg_field* y, double a, const bcg_field* x, double b) {
+  if (!same_shape(y, x)) return BCG_ERR_INVALID;
+  return axpby(y->ctx, y, a, x, b, "axpby");
+}
+int bcg_field_add_matrix(bcg_field* y, const bcg_field* x, const double* M) {
+  if (!same_shape(y, x) || !M || y == x) return BCG_ERR_INVALID;
+  return rmul(y->ctx, y, x, CMat(y->m, M), 0.0, bcg::RMUL_ADD, "block_axpy");
+}
+int bcg_field_rescale_add_matrix(bcg_field* y, const double* M, const bcg_field* x, double b) {
+  if (!same_shape(y, x) || !M) return BCG_ERR_INVALID;
+  return rmul(y->ctx, y, x, CMat(y->m, M), b, bcg::RMUL_XPAY, "block_xpay");
+}
+
+int bcg_field_hermitian_dot(const bcg_field* a, const bcg_field* b, double* out) {
+  if (!same_shape(a, b) || !out) return BCG_ERR_INVALID;
+  CMat G;
+  BCG_TRY(gram(a->ctx, a, b, G));
+  G.store(out);
+  return BCG_OK;
+}
+
+int bcg_field_real_dot(const bcg_field* a, const bcg_field* b, double* out) {
+  if (!same_shape(a, b) || !out) return BCG_ERR_INVALID;
+  if (a->m != 1) BCG_FAIL(a->ctx, BCG_ERR_INVALID, "real_dot is defined for N_rhs = 1 (inc/fields.hpp:93)");
+  CMat G;
+  BCG_TRY(gram(a->ctx, a, b, G, false));
+  *out = G(0, 0).real();
+  return BCG_OK;
+}
+
+int bcg_field_tri_solve_rhs(bcg_field* y, const double* R) {
+  if (!y || !R) return BCG_ERR_INVALID;
+  return trisolve(y->ctx, y, CMat(y->m, R));
+}
+
+int bcg_field_thin_qr(bcg_field* y, double* R_out) {
+  if (!y || !R_out) return BCG_ERR_INVALID;
+  CMat R;
+  BCG_TRY(thin_qr(y->ctx, y, R));
+  R.store(R_out);
+  return BCG_OK;
+}
+
+// ---- operator ----------------------------------------------------------------------------------
+int bcg_gauge_create(bcg_context* c, bcg_gauge** out) {
+  if (!c || !out) return BCG_ERR_INVALID;
+  bcg_gauge* g = new bcg_gauge{c, nullptr, nullptr, false};
+  hipError_t e = hipMalloc(&g->U, static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2));
+  if (e == hipSuccess && c->ghost_sites > 0) e = hipMalloc(&g->Ughost, static_cast<size_t>(c->ghost_sites) * 9 * sizeof(double2));
+  if (e != hipSuccess) {
+    if (g->U) (void)hipFree(g->U);
+    delete g;
+    c->err = std::string("bcg_gauge_create: hipMalloc: ") + hipGetErrorString(e);
+    return BCG_ERR_HIP;
+  }
+  *out = g;
+  return BCG_OK;
+}
+
+int bcg_gauge_destroy(bcg_gauge* g) {
+  if (!g) return BCG_OK;
+  (void)hipStreamSynchronize(g->ctx->stream);
+  (void)hipFree(g->U);
+  if (g->Ughost) (void)hipFree(g->Ughost);
+  delete g;
+  return BCG_OK;
+}
+
+int bcg_gauge_upload(bcg_gauge* g, const double* host) {
+  if (!g || !host) return BCG_ERR_INVALID;
+  bcg_context* c = g->ctx;
+  HIP_TRY(c, hipMemcpyAsync(g->U, host, static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2),
+                            hipMemcpyHostToDevice, c->stream));
+  g->ghost_valid = false;
+  return stream_sync(c);
+}
+
+int bcg_gauge_fill_random(bcg_gauge* g, uint64_t seed) {
+  if (!g) return BCG_ERR_INVALID;
+  bcg_context* c = g->ctx;
+  bcg::launch_fill_gauge(c->stream, c->lat, c->gdims, g->U, seed);
+  g->ghost_valid = false;
+  return check_launch(c, "fill_gauge");
+}
+
+int bcg_dirac_hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in) {
+  if (!c || !g || !same_shape(out, in) || out == in || g->ctx != c || in->ctx != c) return BCG_ERR_INVALID;
+  return hop(c, g, out, in, bcg::HOP_PLAIN, nullptr, 0.0);
+}
+
+int bcg_dirac_apply(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* out, const bcg_field* in) {
+  if (!c || !g || !same_shape(out, in) || out == in || g->ctx != c || in->ctx != c) return BCG_ERR_INVALID;
+  return apply_shifted(c, g, mass, 0.0, out, in);
+}
+
+double bcg_sbcgrq_bytes_per_iteration(const bcg_context* c, int m, int n_shifts) {
+  if (!c) return 0.0;
+  const double s = 48.0 * m, gl = 144.0 * c->ndim;
+  return static_cast<double>(c->lat.V) * ((14.0 + 4.0 * (n_shifts - 1)) * s + 2.0 * gl);
+}
+
+// ---- SBCGrQ (inc/block_solvers.hpp:91-185) -----------------------------------------------------
+// The solver is a resumable state machine so that a caller can run (and time) an exact number of
+// iterations: begin = everything before the while loop (:97-131), iterate = loop bodies, end =
+// release of the work fields.  bcg_sbcgrq_solve is begin + iterate(max_iterations) + end.
+}  // extern "C"
+
+struct bcg_sbcgrq_state {
+  bcg_context* c = nullptr;
+  const bcg_gauge* g = nullptr;
+  double mass = 0.0;
+  int m = 0, n_shifts = 0;
+  std::vector<double> sigma;
+  double eps = 0.0, eps_shifts = 0.0;
+  std::vector<bcg_field*> X;
+  bcg_field* B = nullptr;
+  bcg_field* T = nullptr;
+  bcg_field* Q = nullptr;
+  std::vector<bcg_field*> P;
+  int n_unconverged = 0;
+  CMat alpha, rho, delta, alpha_inv, alpha_inv_old, rho_old;
+  std::vector<CMat> alpha_s, beta_s;
+  std::vector<double> b_norm;
+  double residual = 1.0;
+  int iter = 0;
+};
+
+namespace {
+
+void sbcgrq_release(bcg_sbcgrq_state* st) {
+  if (st->T) bcg_field_destroy(st->T);
+  if (st->Q && st->Q != st->B) bcg_field_destroy(st->Q);
+  for (bcg_field* p : st->P)
+    if (p) bcg_field_destroy(p);
+  st->T = st->Q = nullptr;
+  st->P.clear();
+}
+
+// One pass of the loop body, inc/block_solvers.hpp:133-182.
+int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
+  bcg_context* c = st->c;
+  const int m = st->m, n_shifts = st->n_shifts;
+  const std::vector<double>& sigma = st->sigma;
+  const CMat Identity = CMat::identity(m);
+  // T = (A + sigma_0) P_0                                                    :134-136
+  BCG_TRY(apply_shifted(c, st->g, st->mass, sigma[0], st->T, st->P[0]));
+  ++st->iter;                                            // :137
+  st->alpha_inv_old = st->alpha_inv;                     // :139
+  BCG_TRY(gram(c, st->P[0], st->T, st->alpha_inv));      // :140   (global reduction #1)
+  if (!st->alpha_inv.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "SBCGrQ: P^dagger A P is not finite");
+  st->alpha = bcg::inverse_full_pivot(st->alpha_inv);    // :142
+  const CMat alpha_delta = st->alpha * st->delta;        // :145 uses delta of the previous iteration
+  // Q -= T alpha                                                             :148
+  BCG_TRY(rmul(c, st->Q, st->T, -st->alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));
+  st->rho_old = st->rho;                                 // :150
+  BCG_TRY(thin_qr(c, st->Q, st->rho));                   // :152   (global reduction #2)
+  st->delta = st->rho * st->delta;                       // :153
+  st->residual = max_ratio(st->delta.row_norms(), st->b_norm);  // :155
+  // X_0 += P_0 (alpha delta_old) -- issued after the QR; it only needs the old P_0   :145
+  BCG_TRY(rmul(c, st->X[0], st->P[0], alpha_delta, 0.0, bcg::RMUL_ADD, "block_axpy"));
+  // P_0 = P_0 rho^dagger + Q                                                 :158
+  BCG_TRY(rmul(c, st->P[0], st->Q, st->rho.adjoint(), 1.0, bcg::RMUL_XPAY, "block_xpay"));
+
+  const bool tracing = trace && trace->recorded < trace->capacity;
+  double* tm = nullptr;
+  double* tr = nullptr;
+  const size_t mm2 = static_cast<size_t>(m) * m * 2;
+  if (tracing) {
+    tm = trace->mats ? trace->mats + static_cast<size_t>(trace->recorded) * (3 + 2 * n_shifts) * mm2 : nullptr;
+    tr = trace->res ? trace->res + static_cast<size_t>(trace->recorded) * (1 + n_shifts) : nullptr;
+    if (tm) {
+      std::memset(tm, 0, sizeof(double) * (3 + 2 * n_shifts) * mm2);
+      st->alpha.store(tm);
+      st->rho.store(tm + mm2);
+      st->delta.store(tm + 2 * mm2);
+    }
+    if (tr) {
+      tr[0] = st->residual;
+      for (int s = 0; s < n_shifts; ++s) tr[1 + s] = -1.0;
+    }
+  }
+  const CMat rho_dag = st->rho.adjoint();
+  for (int s = st->n_unconverged - 1; s > 0; --s) {  // :161
+    const CMat beta_s_inv = Identity + (sigma[s] - sigma[0]) * st->alpha +
+                            st->alpha * st->rho_old * st->alpha_inv_old * (Identity - st->beta_s[s]) *
+                                st->rho_old.adjoint();                                                   // :163-165
+    st->beta_s[s] = bcg::inverse_full_pivot(beta_s_inv);                                                 // :166
+    st->alpha_s[s] = st->beta_s[s] * st->alpha * st->rho_old * st->alpha_inv_old * st->alpha_s[s];       // :167-168
+    const double residual_shift = max_ratio((st->rho * st->alpha_inv * st->alpha_s[s]).row_norms(), st->b_norm);  // :169-172
+    BCG_TRY(rmul(c, st->X[s], st->P[s], st->alpha_s[s], 0.0, bcg::RMUL_ADD, "block_axpy"));              // :175
+    BCG_TRY(rmul(c, st->P[s], st->Q, st->beta_s[s] * rho_dag, 1.0, bcg::RMUL_XPAY, "block_xpay"));       // :177
+    if (tm) {
+      st->alpha_s[s].store(tm + (3 + s) * mm2);
+      st->beta_s[s].store(tm + (3 + n_shifts + s) * mm2);
+    }
+    if (tr) tr[1 + s] = residual_shift;
+    if (residual_shift < st->eps_shifts) --st->n_unconverged;  // :179-181
+  }
+  if (tracing) trace->recorded += 1;
+  return BCG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
+                     const double* sigma, double eps, double eps_shifts, int consume_B, bcg_sbcgrq_state** out) {
+  if (!c || !g || !X || !B || !sigma || !out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
+  const int m = B->m;
+  for (int s = 0; s < n_shifts; ++s)
+    if (!same_shape(X[s], B) || X[s] == B) BCG_FAIL(c, BCG_ERR_INVALID, "SBCGrQ: X[s] must be distinct fields of B's width");
+  // :97-101
+  if (sigma[0] < 0.0) BCG_FAIL(c, BCG_ERR_INVALID, "SBCGrQ: shifts must be zero or positive");
+  if (!std::is_sorted(sigma, sigma + n_shifts)) BCG_FAIL(c, BCG_ERR_INVALID, "SBCGrQ: shifts must be in ascending order");
+  BCG_TRY(ensure_scratch(c));
+  bcg_sbcgrq_state* st = new bcg_sbcgrq_state();
+  st->c = c;
+  st->g = g;
+  st->mass = mass;
+  st->m = m;
+  st->n_shifts = n_shifts;
+  st->sigma.assign(sigma, sigma + n_shifts);
+  st->eps = eps;
+  st->eps_shifts = eps_shifts;
+  st->X.assign(X, X + n_shifts);
+  st->B = B;
+  st->n_unconverged = n_shifts;                  // :104
+  const CMat Identity = CMat::identity(m);       // :106
+  st->alpha = st->rho = st->delta = CMat(m);     // :107
+  st->alpha_inv = Identity;                      // :108
+  st->alpha_inv_old = st->rho_old = CMat(m);
+  st->P.assign(n_shifts, nullptr);
+#define BEGIN_TRY(call)          \
+  do {                           \
+    int rc_ = (call);            \
+    if (rc_ != BCG_OK) {         \
+      sbcgrq_release(st);        \
+      delete st;                 \
+      return rc_;                \
+    }                            \
+  } while (0)
+  // T, Q (:109).  T is overwritten before it is read, so it is not initialised from B.
+  BEGIN_TRY(bcg_field_create(c, m, &st->T));
+  if (consume_B) {
+    st->Q = B;
+  } else {
+    BEGIN_TRY(bcg_field_create(c, m, &st->Q));
+    BEGIN_TRY(bcg_field_copy(st->Q, B));
+  }
+  for (int s = 0; s < n_shifts; ++s) BEGIN_TRY(bcg_field_set_zero(X[s]));  // :111-113
+  BEGIN_TRY(thin_qr(c, st->Q, st->delta));                                  // :115
+  st->rho = st->delta;                                                      // :116
+  for (int s = 0; s < n_shifts; ++s) {                                      // :117
+    BEGIN_TRY(bcg_field_create(c, m, &st->P[s]));
+    BEGIN_TRY(bcg_field_copy(st->P[s], st->Q));
+  }
+#undef BEGIN_TRY
+  st->alpha_s.assign(n_shifts, Identity);  // :122
+  st->beta_s.assign(n_shifts, Identity);   // :123
+  st->iter = 0;                            // :126
+  st->b_norm = st->delta.row_norms();      // :130
+  st->residual = 1.0;                      // :131
+  *out = st;
+  return BCG_OK;
+}
+
+int bcg_sbcgrq_iterate(bcg_sbcgrq_state* st, int max_new_iterations, int* iterations_total, double* residual_out,
+                       bcg_sbcgrq_trace* trace) {
+  if (!st) return BCG_ERR_INVALID;
+  int done = 0;
+  while (st->residual > st->eps && done < max_new_iterations) {  // :132
+    BCG_TRY(sbcgrq_iteration(st, trace));
+    ++done;
+  }
+  BCG_TRY(stream_sync(st->c));
+  if (iterations_total) *iterations_total = st->iter;
+  if (residual_out) *residual_out = st->residual;
+  return BCG_OK;
+}
+
+int bcg_sbcgrq_end(bcg_sbcgrq_state* st) {
+  if (!st) return BCG_OK;
+  (void)stream_sync(st->c);
+  sbcgrq_release(st);
+  delete st;
+  return BCG_OK;
+}
+
+int bcg_sbcgrq_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
+                     const double* sigma, double eps, double eps_shifts, int max_iterations, int consume_B,
+                     int* iterations_out, double* residual_out, bcg_sbcgrq_trace* trace) {
+  bcg_sbcgrq_state* st = nullptr;
+  if (trace) trace->recorded = 0;
+  BCG_TRY(bcg_sbcgrq_begin(c, g, mass, X, B, n_shifts, sigma, eps, eps_shifts, consume_B, &st));
+  const int rc = bcg_sbcgrq_iterate(st, max_iterations, iterations_out, residual_out, trace);  // :184
+  bcg_sbcgrq_end(st);
+  return rc;
+}
+
+}  // extern "C"

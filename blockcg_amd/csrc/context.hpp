@@ -1,0 +1,74 @@
+// Context, field and gauge objects behind the opaque handles of include/blockcg_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/blockcg_hip.h"
+#include "kernels.hpp"
+#include "small_matrix.hpp"
+
+struct bcg_field {
+  bcg_context* ctx;
+  int m;
+  double2* d;  // [V_local*3][m]
+};
+
+struct bcg_gauge {
+  bcg_context* ctx;
+  double2* U;       // [V_local][ndim][9]
+  double2* Ughost;  // [ghost sites][9], only the minus faces are filled
+  bool ghost_valid;
+};
+
+namespace bcg {
+
+struct ProfEntry {
+  double ms = 0.0;
+  long count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace bcg
+
+struct bcg_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int ndim = 1;
+  int gdims[4] = {1, 1, 1, 1};
+  int grid[4] = {1, 1, 1, 1};
+  int coords[4] = {0, 0, 0, 0};
+  bcg::LatticeDev lat{};
+  int64_t ghost_sites = 0;  // total ghost sites over all split directions (both faces)
+  bool distributed = false;
+  bcg_comm comm{};
+  bool have_comm = false;
+  bool force_generic = false;
+
+  // scratch
+  std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)
+  double2* halo_send = nullptr;
+  double2* halo_recv = nullptr;
+  size_t halo_bytes = 0;
+  double2* partials = nullptr;           // block partials of Gram products
+  size_t partials_bytes = 0;
+  double2* dev_mats = nullptr;           // ring of coefficient-matrix slots in device memory
+  double* pin_mats = nullptr;            // pinned host mirror of the ring
+  size_t mat_slot_bytes = 0;
+  int mat_slots = 0, mat_next = 0, mat_in_flight = 0;
+  double2* dev_gram = nullptr;           // reduced Gram matrix (device), all-reduced in place
+  double* pin_gram = nullptr;            // pinned host copy
+  double2* staging = nullptr;            // upload/download layout-conversion staging
+  size_t staging_bytes = 0;
+
+  // profiling
+  bool profiling = false;
+  std::map<std::string, bcg::ProfEntry> prof;
+  std::vector<hipEvent_t> event_pool;
+  std::string prof_json;
+
+  mutable std::string err;
+};

@@ -1,0 +1,172 @@
+/* blockcg_hip.h -- C ABI of libblockcg_hip.so: the MI355X (gfx950) SBCGrQ hot path.
+ *
+ * This is the drop-in boundary for the iteration hot path of lkeegan/blockCG.  The reference has no
+ * FFI: its boundary is the header-level C++ API of inc/fields.hpp, inc/dirac_op.hpp and
+ * inc/block_solvers.hpp.  Every entry point below names the reference interface it replaces
+ * (file:line relative to the reference root).  The C++ classes with the reference's names
+ * (blockcg_amd/include/blockcg/{fields,dirac_op,block_solvers}.hpp) are thin wrappers over these
+ * calls; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no C++ or torch types.  Every call returns an int status
+ *    (BCG_OK = 0); the reference's assert-only error convention (inc/block_solvers.hpp:97-101)
+ *    cannot cross a C ABI.  bcg_last_error() returns a message for the last failure on the context.
+ *  - Scalars are complex<double> stored as interleaved (re, im) doubles.
+ *  - HOST layouts at this boundary are the reference's in-memory layouts:
+ *      block field  [site][rhs j][colour c]      48*m bytes per site   inc/fields.hpp:19-20,28-30
+ *      m x m matrix column-major (i,j) at j*m+i                         inc/fields.hpp:22-23
+ *      gauge links  [site][mu < ndim][3x3 column-major]  144 B per link inc/dirac_op.hpp:10-11
+ *    Device layouts are private to the library: fields are [site][colour][rhs] so that
+ *    one (site, colour) row of m complex numbers is contiguous.
+ *  - Site counts and byte offsets are 64-bit: 128^4 sites fit in int, 128^4 * 768 B does not.
+ *  - Block width m (the reference's template parameter N_rhs) is a run-time argument; supported
+ *    widths: 1, 2, 3, 4, 6, 8, 12, 16, 32 (BCG_ERR_UNSUPPORTED otherwise).
+ *  - Lattice: up to 4 dimensions, lexicographic site order with x0 fastest, periodic.  ndim = 1,
+ *    dims = {V} is exactly the reference's 1-D operator (inc/dirac_op.hpp:14-21); the n-D operator
+ *    is  (D psi)(x) = 1/2 sum_mu eta_mu(x) [U_mu(x) psi(x+mu) - U_mu(x-mu)^dagger psi(x-mu)],
+ *    eta_mu(x) = (-1)^(x_0+...+x_{mu-1})  (global coordinates).
+ *  - One context = one GPU = one rank of a process grid.  With grid = {1,1,1,1} nothing
+ *    communicates.  With more ranks the caller supplies two callbacks (bcg_comm) that move halo
+ *    faces and sum m x m partials; bench.py implements them with torch.distributed (RCCL).
+ *  - All work is enqueued on the context's HIP stream; calls that return host data synchronize it.
+ */
+#ifndef BLOCKCG_HIP_H
+#define BLOCKCG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCG_OK 0
+#define BCG_ERR_INVALID 1     /* bad argument (null pointer, size mismatch, unsorted shifts ...) */
+#define BCG_ERR_UNSUPPORTED 2 /* block width or lattice shape not instantiated */
+#define BCG_ERR_HIP 3         /* a HIP runtime call failed; see bcg_last_error */
+#define BCG_ERR_NO_DEVICE 4   /* no usable gfx950 device */
+#define BCG_ERR_COMM 5        /* a communication callback failed or is missing */
+#define BCG_ERR_NUMERIC 6     /* non-finite or non-positive-definite Gram matrix (CholQR breakdown) */
+
+typedef struct bcg_context bcg_context;
+typedef struct bcg_field bcg_field; /* device block field: V_local sites x 3 colours x m columns */
+typedef struct bcg_gauge bcg_gauge; /* device gauge links of a dirac_op */
+
+/* ---- communication callbacks (multi-GPU only) ------------------------------------------------
+ * halo_exchange: the library has packed 2 faces per split direction into the send buffer and now
+ *   needs the matching faces of the neighbour ranks in the receive buffer.  Buffers are device
+ *   memory owned by the library (bcg_halo_buffers).  n_msgs messages; message k sends
+ *   send_bytes[k] bytes at send_offset[k] to rank peer_send[k] and receives the same number of bytes
+ *   at recv_offset[k] from rank peer_recv[k]; messages to one peer must match in posting order.
+ *   The exchange must be ordered after prior work on the context's stream and complete (or be
+ *   stream-ordered) before later work on it.
+ * allreduce_sum: sum `count` doubles at device pointer `buf` over all ranks, in place, identically
+ *   on every rank, stream-ordered as above. */
+typedef struct bcg_comm {
+  void* user;
+  int (*halo_exchange)(void* user, int n_msgs, const int* peer_send, const int* peer_recv, const size_t* send_offset,
+                       const size_t* recv_offset, const size_t* nbytes);
+  int (*allreduce_sum)(void* user, void* buf, size_t count);
+} bcg_comm;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device: HIP device ordinal.  stream: a hipStream_t to enqueue on, or NULL for a private stream.
+ * ndim, global_dims[ndim]: the whole lattice.  grid[ndim]: ranks per direction (NULL = all 1);
+ * coords[ndim]: this rank's position (NULL = all 0).  global_dims[mu] % grid[mu] must be 0. */
+int bcg_context_create(bcg_context** ctx, int device, void* stream, int ndim, const int* global_dims, const int* grid,
+                       const int* coords);
+int bcg_context_destroy(bcg_context* ctx);
+const char* bcg_last_error(const bcg_context* ctx); /* ctx may be NULL: last creation error */
+int bcg_context_set_comm(bcg_context* ctx, const bcg_comm* comm);
+int64_t bcg_local_volume(const bcg_context* ctx);
+int bcg_local_dims(const bcg_context* ctx, int* dims4_out, int* origin4_out);
+/* Device halo buffers (valid after the first field of width m was created); for wrapping as
+ * communicator-visible tensors. */
+int bcg_halo_buffers(bcg_context* ctx, void** send, void** recv, size_t* bytes_each);
+int bcg_synchronize(bcg_context* ctx);
+/* Per-kernel timing with HIP events on the context's stream (off by default).  Names and
+ * accumulated milliseconds / launch counts are returned as a JSON string owned by the context. */
+int bcg_profiling(bcg_context* ctx, int enable);
+const char* bcg_profile_json(bcg_context* ctx);
+int bcg_profile_reset(bcg_context* ctx);
+/* Force the generic (any-m, VALU) kernels even where an MFMA fast path exists; for parity tests. */
+int bcg_force_generic(bcg_context* ctx, int enable);
+
+/* ---- fields: block_fermion_field<N_rhs> (inc/fields.hpp:25-147) --------------------------- */
+int bcg_field_create(bcg_context* ctx, int m, bcg_field** f);          /* explicit ctor :35 (contents undefined) */
+int bcg_field_destroy(bcg_field* f);
+int bcg_field_width(const bcg_field* f);
+int bcg_field_upload(bcg_field* f, const double* host);                 /* host -> device, layout conversion */
+int bcg_field_download(const bcg_field* f, double* host);               /* device -> host */
+int bcg_field_copy(bcg_field* dst, const bcg_field* src);               /* copy-construct / assignment */
+int bcg_field_set_zero(bcg_field* f);                                   /* setZero :57-61 */
+/* i.i.d. uniform [-1,1) per real component from the counter-based generator shared with the
+ * oracle (value depends on seed and GLOBAL element index only); stands in for setRandom :62-66 */
+int bcg_field_fill_random(bcg_field* f, uint64_t seed);
+int bcg_field_add_assign(bcg_field* y, const bcg_field* x);             /* operator+= :40-46 */
+int bcg_field_sub_assign(bcg_field* y, const bcg_field* x);             /* operator-= :47-53  (K9) */
+int bcg_field_add_scalar(bcg_field* y, const bcg_field* x, double a);   /* add(rhs, double) :70-77  (K3) */
+int bcg_field_add_matrix(bcg_field* y, const bcg_field* x, const double* M); /* add(rhs, m x m) :70-77  (K5) */
+/* rescale_add :79-90:  y = y*a + x*b  (K2) ;  y = y*M + x*b  (K6) */
+int bcg_field_rescale_add_scalar(bcg_field* y, double a, const bcg_field* x, double b);
+int bcg_field_rescale_add_matrix(bcg_field* y, const double* M, const bcg_field* x, double b);
+/* hermitian_dot :103-122: out = a^dagger b (m x m, column-major), lower triangle mirrored so the
+ * result is exactly Hermitian; summed over all ranks.  (K4) */
+int bcg_field_hermitian_dot(const bcg_field* a, const bcg_field* b, double* out);
+int bcg_field_real_dot(const bcg_field* a, const bcg_field* b, double* out); /* real_dot :93-99, m = 1 */
+/* multiply_upper_triangular_inverse_RHS :125-136:  y <- y R^{-1}, R upper triangular  (K7) */
+int bcg_field_tri_solve_rhs(bcg_field* y, const double* R);
+/* thinQR :140-146:  R = chol(y^dagger y)^dagger ; y <- y R^{-1}.  BCG_ERR_NUMERIC if the Gram
+ * matrix is not positive definite (the reference would silently produce NaN). */
+int bcg_field_thin_qr(bcg_field* y, double* R_out);
+
+/* ---- operator: dirac_op (inc/dirac_op.hpp:8-44) --------------------------------------------- */
+int bcg_gauge_create(bcg_context* ctx, bcg_gauge** g);
+int bcg_gauge_destroy(bcg_gauge* g);
+int bcg_gauge_upload(bcg_gauge* g, const double* host);      /* local sites, [site][mu][3x3 col-major] */
+int bcg_gauge_fill_random(bcg_gauge* g, uint64_t seed);      /* stands in for the ctor's setRandom :27-32 */
+/* private D :14-21 (exposed for tests):  out = D in */
+int bcg_dirac_hop(bcg_context* ctx, const bcg_gauge* g, bcg_field* out, const bcg_field* in);
+/* op :36-43:  out = mass^2 in - D(D(in)).  The reference allocates a temporary per call (:39);
+ * here the context owns one scratch field per width. */
+int bcg_dirac_apply(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* out, const bcg_field* in);
+
+/* ---- solver: SBCGrQ (inc/block_solvers.hpp:91-185) ------------------------------------------ */
+typedef struct bcg_sbcgrq_trace {
+  /* Optional per-iteration record for the first `capacity` iterations; arrays owned by caller.
+   * mats: [capacity][3 + 2*n_shifts][m*m] complex column-major = alpha, rho, delta, alpha_s[], beta_s[]
+   * res : [capacity][1 + n_shifts] doubles = residual, residual_shift[] (-1 = shift not visited) */
+  int capacity;
+  int recorded;
+  double* mats;
+  double* res;
+} bcg_sbcgrq_trace;
+
+/* X[n_shifts] must be fields of B's width; they are overwritten (zeroed first, :111-113).
+ * sigma must be non-negative and ascending (:99-101) else BCG_ERR_INVALID.
+ * eps = eps_shifts = 0 with a finite max_iterations is the fixed-work benchmark mode.
+ * consume_B != 0 lets the solver use B's storage as its residual block Q (B is destroyed
+ * logically; saves one field of memory at 128^4).  *iterations_out = operator applications (:184). */
+int bcg_sbcgrq_solve(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
+                     const double* sigma, double eps, double eps_shifts, int max_iterations, int consume_B,
+                     int* iterations_out, double* residual_out, bcg_sbcgrq_trace* trace);
+
+/* The same solver as a resumable state machine, so a caller can run (and time) an exact number of
+ * iterations: begin = everything before the loop (:97-131); iterate = at most max_new_iterations
+ * passes of the loop body (:132-182), stopping early when residual <= eps; end releases the work
+ * fields.  X and B must outlive the state. */
+typedef struct bcg_sbcgrq_state bcg_sbcgrq_state;
+int bcg_sbcgrq_begin(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
+                     const double* sigma, double eps, double eps_shifts, int consume_B, bcg_sbcgrq_state** state);
+int bcg_sbcgrq_iterate(bcg_sbcgrq_state* state, int max_new_iterations, int* iterations_total, double* residual_out,
+                       bcg_sbcgrq_trace* trace);
+int bcg_sbcgrq_end(bcg_sbcgrq_state* state);
+
+/* Algorithmic HBM bytes of one SBCGrQ iteration on this rank's sub-lattice:
+ *   V_local * [ (14 + 4*(S-1)) * 48*m + 2 * 144*ndim ] */
+double bcg_sbcgrq_bytes_per_iteration(const bcg_context* ctx, int m, int n_shifts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOCKCG_HIP_H */

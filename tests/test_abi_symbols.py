@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports exactly the
+entry points include/blockcg_hip.h declares, and refuses to run without a gfx950 device (no CPU
+fallback).  No compute call is made here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import blockcg_amd
+    if not os.path.exists(blockcg_amd.LIB_PATH):
+        blockcg_amd.build()
+    return blockcg_amd.load()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "blockcg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bcg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/blockcg_hip.h but not exported"
+
+
+def test_bindings_cover_the_header():
+    from blockcg_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_library_contains_gfx950_code_object():
+    import blockcg_amd
+    data = open(blockcg_amd.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data
+    assert b"gfx942" not in data and b"sm_" not in data  # one target, no dual paths
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from blockcg_amd import BlockCGError, Context
+    with pytest.raises(BlockCGError) as e:
+        Context([16])
+    assert e.value.code == 4  # BCG_ERR_NO_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    # the oracle is test infrastructure; nothing under blockcg_amd/ may reference it
+    for dp, _, fns in os.walk(os.path.join(ROOT, "blockcg_amd")):
+        if "_build" in dp:
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), fn
+                assert not re.search(r'#include\s+"[^"]*oracle/', txt), fn

@@ -1,0 +1,214 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against
+  (1) golden fixtures computed by the unmodified reference (tests/golden/*.npz),
+  (2) the CPU oracle on the same seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances are the fp64 ones of SURVEY.md Appendix F (tests/conftest.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import TOL_COEFF, TOL_KERNEL, TOL_SOLUTION, golden_files, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FULL = [f for f in golden_files() if "8x8x8x8" not in f]
+WITH_PRIMS = [f for f in FULL if "v1000" not in f]
+
+
+@pytest.fixture(scope="module")
+def bc():
+    import blockcg_amd
+    return blockcg_amd
+
+
+def _dims(g):
+    return [int(d) for d in g["dims"]]
+
+
+def _setup(bc, g):
+    ctx = bc.Context(_dims(g))
+    D = bc.dirac_op(ctx, float(g["mass"]), U=g["U"])
+    return ctx, D
+
+
+@pytest.mark.parametrize("path", WITH_PRIMS, ids=os.path.basename)
+def test_primitives_match_reference_fixture(bc, path):
+    g = np.load(path)
+    ctx, D = _setup(bc, g)
+    m = g["B"].shape[1]
+    F = lambda a: bc.block_fermion_field(ctx, m, a)  # noqa: E731
+    B, Y, M = g["B"], g["Y"], g["M"]
+    # upload / download round trip is exact
+    assert np.array_equal(F(B).download(), B)
+    out = bc.block_fermion_field(ctx, m)
+    D.op(out, F(B))
+    assert rel_err(out.download(), g["op_B"]) < TOL_KERNEL
+    assert rel_err(F(Y).add(F(B), 0.3).download(), g["add_scalar_0p3"]) < TOL_KERNEL
+    assert rel_err(F(Y).rescale_add(-1.0, F(B), 0.25).download(), g["rescale_add_scalar_m1_0p25"]) < TOL_KERNEL
+    assert rel_err(F(Y).add(F(B), M).download(), g["add_matrix"]) < TOL_KERNEL
+    assert rel_err(F(Y).rescale_add(M, F(B), 1.0).download(), g["rescale_add_matrix_1"]) < TOL_KERNEL
+    assert rel_err(F(Y).hermitian_dot(F(B)), g["hermitian_dot_YB"]) < TOL_KERNEL
+    fy = F(Y)
+    G = fy.hermitian_dot(fy)
+    assert rel_err(G, g["hermitian_dot_YY"]) < TOL_KERNEL
+    assert np.array_equal(np.triu(G, 1), np.conj(np.tril(G, -1)).T)  # exactly Hermitian, inc/fields.hpp:115-120
+    q = F(Y)
+    R = q.thinQR()
+    assert rel_err(R, g["thinqr_R"]) < TOL_KERNEL
+    assert rel_err(q.download(), g["thinqr_Q"]) < 1e-12
+    assert rel_err(F(B).multiply_upper_triangular_inverse_RHS(g["thinqr_R"]).download(), g["tri_solve"]) < TOL_KERNEL
+    fy = F(Y)
+    fy -= F(B)
+    assert rel_err(fy.download(), g["sub"]) < TOL_KERNEL
+    fy += F(B)
+    assert rel_err(fy.download(), Y) < TOL_KERNEL
+
+
+@pytest.mark.parametrize("path", FULL, ids=os.path.basename)
+def test_solver_matches_reference_fixture(bc, orc, path):
+    g = np.load(path)
+    ctx, D = _setup(bc, g)
+    m = g["B"].shape[1]
+    dims, mass, shifts = _dims(g), float(g["mass"]), list(g["shifts"])
+    eps, eps_s = float(g["eps"]), float(g["eps_shifts"])
+    B = bc.block_fermion_field(ctx, m, g["B"])
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    info = bc.SBCGrQ(X, B, D, shifts, eps, eps_s, trace_limit=5, return_info=True)
+    ref_it = int(g["iterations"])
+    slack = max(1, int(0.02 * ref_it)) if mass < 0.01 else 1
+    assert abs(info["iterations"] - ref_it) <= slack
+    Xh = np.stack([x.download() for x in X])
+    # the reference's acceptance criterion, recomputed independently on the CPU (test/solvers.cpp:104-116)
+    res = orc.true_residuals(g["U"], dims, mass, g["B"], shifts, Xh)
+    assert res[0].max() < 2 * eps
+    assert np.all(res < np.maximum(2 * eps, 4 * g["residuals"]))
+    if info["iterations"] == ref_it and mass >= 0.05:
+        assert rel_err(Xh, g["X"]) < TOL_SOLUTION
+    # coefficient matrices of the first iterations against the oracle (pinned to the reference)
+    o = orc.sbcgrq(g["U"], dims, mass, g["B"], shifts, eps, eps_s, max_iterations=5, trace_limit=5)
+    n = min(5, info["iterations"])
+    for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+        assert rel_err(info["trace"][key][:n], o["trace"][key][:n]) < TOL_COEFF, key
+    assert np.allclose(info["trace"]["residual"][:n], o["trace"]["residual"][:n], rtol=1e-9)
+
+
+@pytest.mark.parametrize("path", WITH_PRIMS, ids=os.path.basename)
+def test_early_iterates_match_reference_fixture(bc, path):
+    g = np.load(path)
+    ctx, D = _setup(bc, g)
+    m = g["B"].shape[1]
+    shifts = list(g["shifts"])
+    k = 1
+    while f"X_after_{k}" in g.files:
+        B = bc.block_fermion_field(ctx, m, g["B"])
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        assert bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=k) == k
+        assert rel_err(np.stack([x.download() for x in X]), g[f"X_after_{k}"]) < 1e-12
+        k += 1
+
+
+def test_generator_matches_oracle_bit_for_bit(bc, orc):
+    dims = [6, 4, 2, 3]
+    ctx = bc.Context(dims)
+    f = bc.block_fermion_field(ctx, 3).setRandom(seed=42)
+    assert np.array_equal(f.download(), orc.fill_field(3, ctx.V, 42))
+    D = bc.dirac_op(ctx, 0.1, seed=7)
+    U = orc.fill_gauge(dims, 7)
+    x = orc.fill_field(3, ctx.V, 42)
+    out = bc.block_fermion_field(ctx, 3)
+    D.op(out, f)
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.1, x)) < TOL_KERNEL
+
+
+@pytest.mark.parametrize("m,dims,S", [(16, [8, 8, 8, 8], 4), (8, [16, 8, 8, 4], 1), (32, [4, 4, 4, 4], 8), (2, [5, 3, 7], 3),
+                                      (6, [10, 6], 2)])
+def test_fixed_work_against_oracle(bc, orc, m, dims, S):
+    """Seeded synthetic inputs, 6 fixed iterations: every X_s and every coefficient against the oracle."""
+    mass = 0.05
+    shifts = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0][:S]
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, seed=3)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=4)
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    info = bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=6, trace_limit=6, return_info=True)
+    U = orc.fill_gauge(dims, 3)
+    Bh = orc.fill_field(m, ctx.V, 4)
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=6, trace_limit=6)
+    assert info["iterations"] == o["iterations"] == 6
+    assert rel_err(np.stack([x.download() for x in X]), o["X"]) < 1e-11
+    for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+        assert rel_err(info["trace"][key], o["trace"][key]) < TOL_COEFF, key
+
+
+def test_config1_32c4_m8_solves_to_tolerance(bc):
+    """BASELINE.json config 1 (V=32^4, m=8, 1 shift): the reference's acceptance test computed with
+    device primitives (op, add, -=, hermitian_dot), plus operator properties at full size."""
+    dims, m, mass, eps = [32, 32, 32, 32], 8, 0.2, 1e-10
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, seed=11)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=12)
+    X = [bc.block_fermion_field(ctx, m)]
+    it = bc.SBCGrQ(X, B, D, [0.0], eps)
+    assert 0 < it < 2000
+    AX = bc.block_fermion_field(ctx, m)
+    D.op(AX, X[0])
+    AX -= B
+    r2 = np.real(np.diag(AX.hermitian_dot(AX)))
+    b2 = np.real(np.diag(B.hermitian_dot(B)))
+    assert np.sqrt(r2 / b2).max() < 2 * eps
+    # A is Hermitian positive definite: <B, A X> = <A B, X>, and <B, A B> > 0
+    AB = bc.block_fermion_field(ctx, m)
+    D.op(AB, B)
+    lhs = B.hermitian_dot(AX.rescale_add(1.0, B, 1.0))  # AX was A X - B; add B back -> A X
+    rhs = AB.hermitian_dot(X[0])
+    assert rel_err(lhs, rhs) < 1e-10
+    assert np.all(np.real(np.diag(B.hermitian_dot(AB))) > 0)
+    # thinQR leaves orthonormal columns
+    Q = B.copy()
+    R = Q.thinQR()
+    assert rel_err(Q.hermitian_dot(Q), np.eye(m)) < 1e-12
+    assert np.allclose(np.tril(R, -1), 0)
+
+
+def test_config2_64c4_m16_4shifts_solves_to_tolerance(bc):
+    """BASELINE.json config 2 (V=64^4, m=16, 4 shifts): full-size solve, true residual of every shift."""
+    dims, m, mass, eps = [64, 64, 64, 64], 16, 0.3, 1e-9
+    shifts = [0.0, 1e-6, 1e-4, 1e-2]
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, seed=21)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=22)
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    it = bc.SBCGrQ(X, B, D, shifts, eps, eps)
+    assert 0 < it < 1000
+    b2 = np.real(np.diag(B.hermitian_dot(B)))
+    AX = bc.block_fermion_field(ctx, m)
+    for s, sig in enumerate(shifts):
+        D.op(AX, X[s])
+        AX.add(X[s], sig)
+        AX -= B
+        r2 = np.real(np.diag(AX.hermitian_dot(AX)))
+        assert np.sqrt(r2 / b2).max() < 2 * eps, s
+
+
+def test_error_behaviour(bc):
+    ctx = bc.Context([16])
+    D = bc.dirac_op(ctx, 0.5, seed=1)
+    B = bc.block_fermion_field(ctx, 3).setRandom(seed=2)
+    X = [bc.block_fermion_field(ctx, 3) for _ in range(2)]
+    with pytest.raises(bc.BlockCGError) as e:  # unsorted shifts, inc/block_solvers.hpp:100-101
+        bc.SBCGrQ(X, B, D, [0.1, 0.0], 1e-10)
+    assert e.value.code == 1
+    with pytest.raises(bc.BlockCGError):  # negative shift, :99
+        bc.SBCGrQ(X, B, D, [-0.1, 0.0], 1e-10)
+    with pytest.raises(bc.BlockCGError) as e:  # width not instantiated
+        bc.block_fermion_field(ctx, 5)
+    assert e.value.code == 2
+    # CholQR breakdown is reported, not silently NaN (a zero block has a singular Gram matrix)
+    Z = bc.block_fermion_field(ctx, 3).setZero()
+    with pytest.raises(bc.BlockCGError) as e:
+        Z.thinQR()
+    assert e.value.code == 6
+    # non-convergence = return value equals max_iterations
+    assert bc.SBCGrQ(X, B, D, [0.0, 0.1], 1e-300, 1e-300, max_iterations=3) == 3
