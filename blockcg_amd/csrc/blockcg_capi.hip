@@ -9,10 +9,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
 #include "context.hpp"
+#include "kernels_mfma.hpp"
 
 using bcg::CMat;
 using bcg::cd;
@@ -244,28 +246,48 @@ int halo_gauge(bcg_context* c, bcg_gauge* g) {
 // ---- building blocks ---------------------------------------------------------------------------
 bool same_shape(const bcg_field* a, const bcg_field* b) { return a && b && a->ctx == b->ctx && a->m == b->m; }
 
+// x2 chunk for the stencil's cache-blocked walk: three x3-slices of a chunk (plus the streamed output
+// and links) should stay inside the 256 MiB Infinity Cache, so one slice of the chunk is kept <= 24 MiB.
+int hop_c2_for(const bcg_context* c, int m) {
+  if (c->hop_c2 >= 0) return c->hop_c2;
+  if (c->ndim != 4) return 0;
+  const double plane = static_cast<double>(c->lat.L[0]) * c->lat.L[1] * 48.0 * m;
+  int best = 0;
+  for (int d = 1; d <= c->lat.L[2]; ++d)
+    if (c->lat.L[2] % d == 0 && plane * d <= 24.0 * 1024 * 1024) best = d;
+  return best == c->lat.L[2] ? 0 : best;  // whole extent fits: plain lexicographic order is the same walk
+}
+
+inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }
+inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
+constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
+
+// out = D in  (HOP_PLAIN)  or  out = c0*p - D in  (HOP_SHIFTED).  With gram_blocks != nullptr (m = 16 fast
+// path, HOP_SHIFTED) the kernel also leaves block partials of p^dagger out in c->partials.
 int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
-        double c0) {
+        double c0, int* gram_blocks = nullptr) {
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
   BCG_TRY(halo_field(c, in));
-  {
+  const int m = in->m;
+  if (gram_blocks) *gram_blocks = 0;
+  if (fast_hop(c, m)) {
+    const bool gram = gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
+    if (gram) BCG_TRY(ensure_scratch(c));
+    ProfScope ps(c, gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted"));
+    const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, hop_c2_for(c, m));
+    if (gram) *gram_blocks = nb;
+  } else {
     ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
-    bcg::launch_hop_generic(c->stream, in->m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+    bcg::launch_hop_generic(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                             p ? p->d : nullptr, c0);
   }
   return check_launch(c, "hop");
 }
 
-// G = a^dagger b summed over all ranks, Hermitian-mirrored exactly as inc/fields.hpp:115-120.
-int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool mirror = true) {
-  BCG_TRY(ensure_scratch(c));
-  const int m = a->m;
-  int nblocks;
-  {
-    ProfScope ps(c, a == b ? "gram_self" : "gram_pair");
-    nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(c), a->d, b->d, c->partials, kMaxGramBlocks);
-  }
-  BCG_TRY(check_launch(c, "gram"));
+// Block partials in c->partials -> G (m x m), summed over blocks in a fixed order and over ranks,
+// Hermitian-mirrored exactly as inc/fields.hpp:115-120.
+int finish_gram(bcg_context* c, int m, int nblocks, CMat& G, bool mirror) {
   {
     ProfScope ps(c, "reduce_partials");
     bcg::launch_reduce_partials(c->stream, m * m, nblocks, c->partials, c->dev_gram);
@@ -287,12 +309,27 @@ int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool m
   return BCG_OK;
 }
 
+// G = a^dagger b
+int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool mirror = true) {
+  BCG_TRY(ensure_scratch(c));
+  const int m = a->m;
+  int nblocks;
+  {
+    ProfScope ps(c, a == b ? "gram_self" : "gram_pair");
+    if (fast_rows(c, m)) nblocks = bcg::launch_gram_mfma(c->stream, m, rows_of(c), a->d, b->d, c->partials, kFastBlocks);
+    else nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(c), a->d, b->d, c->partials, kMaxGramBlocks);
+  }
+  BCG_TRY(check_launch(c, "gram"));
+  return finish_gram(c, m, nblocks, G, mirror);
+}
+
 int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double b, bcg::RmulMode mode, const char* name) {
   const double2* Md;
   BCG_TRY(upload_mat(c, M, &Md));
   {
     ProfScope ps(c, name);
-    bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
+    if (fast_rows(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
+    else bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
   }
   return check_launch(c, name);
 }
@@ -329,11 +366,79 @@ int get_tmp(bcg_context* c, int m, bcg_field** out) {
 }
 
 // T = (mass^2 + sigma0) P - D(D(P))   [op + add(P, sigma0), inc/block_solvers.hpp:134-136]
-int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P) {
+int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
+                  int* gram_blocks = nullptr) {
   bcg_field* tmp;
   BCG_TRY(get_tmp(c, P->m, &tmp));
   BCG_TRY(hop(c, g, tmp, P, bcg::HOP_PLAIN, nullptr, 0.0));
-  return hop(c, g, T, tmp, bcg::HOP_SHIFTED, P, mass * mass + sigma0);
+  return hop(c, g, T, tmp, bcg::HOP_SHIFTED, P, mass * mass + sigma0, gram_blocks);
+}
+
+// Phase A of an iteration: T = (A + sigma0) P ; G = P^dagger T   (:134-140)
+int phase_A(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P, CMat& G) {
+  int nb = 0;
+  BCG_TRY(apply_shifted(c, g, mass, sigma0, T, P, &nb));
+  if (nb > 0) return finish_gram(c, P->m, nb, G, true);
+  return gram(c, P, T, G);
+}
+
+// Phase B: Q -= T alpha ; G2 = Q^dagger Q   (:148 and the Gram half of :152)
+int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double b, bcg::RmulMode mode, const char* name);
+int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha, CMat& G2) {
+  const int m = Q->m;
+  if (!fast_rows(c, m)) {
+    BCG_TRY(rmul(c, Q, T, -alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));
+    return gram(c, Q, Q, G2);
+  }
+  const CMat na = -alpha;
+  const double2* Md;
+  BCG_TRY(upload_mat(c, na, &Md));
+  int nb;
+  {
+    ProfScope ps(c, "phaseB");
+    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, kFastBlocks);
+  }
+  BCG_TRY(check_launch(c, "phaseB"));
+  return finish_gram(c, m, nb, G2, true);
+}
+
+// Phase C: Q <- Q rho^{-1} ; X_s += P_s A_s ; P_s <- P_s B_s + Q for the n active shifts
+// (:152 second half, :145, :158, :175, :177)
+int trisolve(bcg_context* c, bcg_field* y, const CMat& R);
+int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, bcg_field* const* P, int n,
+            const std::vector<CMat>& A, const std::vector<CMat>& Bm) {
+  const int m = Q->m;
+  if (!fast_rows(c, m)) {
+    BCG_TRY(trisolve(c, Q, rho));
+    for (int s = 0; s < n; ++s) {
+      BCG_TRY(rmul(c, X[s], P[s], A[s], 0.0, bcg::RMUL_ADD, "block_axpy"));
+      BCG_TRY(rmul(c, P[s], Q, Bm[s], 1.0, bcg::RMUL_XPAY, "block_xpay"));
+    }
+    return BCG_OK;
+  }
+  const CMat Rinv = bcg::upper_triangular_inverse(rho);
+  const int per = bcg::phaseC_max_shifts(m);
+  for (int s0 = 0, first = 1; first || s0 < n; s0 += per, first = 0) {
+    const int ns = std::min(per, n - s0);
+    std::vector<const CMat*> mats;
+    mats.push_back(&Rinv);
+    double2* Xp[8];
+    double2* Pp[8];
+    for (int k = 0; k < ns; ++k) {
+      mats.push_back(&A[s0 + k]);
+      mats.push_back(&Bm[s0 + k]);
+      Xp[k] = X[s0 + k]->d;
+      Pp[k] = P[s0 + k]->d;
+    }
+    const double2* Md;
+    BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
+    {
+      ProfScope ps(c, "phaseC");
+      bcg::launch_phaseC(c->stream, m, rows_of(c), Q->d, Xp, Pp, ns, Md, first, kFastBlocks);
+    }
+    BCG_TRY(check_launch(c, "phaseC"));
+  }
+  return BCG_OK;
 }
 
 // thinQR (inc/fields.hpp:140-146)
@@ -412,6 +517,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
     }
   }
   c->ghost_sites = ghost;
+  c->hop_c2 = -1;
+  if (const char* e = std::getenv("BCG_HOP_C2")) c->hop_c2 = std::atoi(e);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -766,24 +873,21 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
   const int m = st->m, n_shifts = st->n_shifts;
   const std::vector<double>& sigma = st->sigma;
   const CMat Identity = CMat::identity(m);
-  // T = (A + sigma_0) P_0                                                    :134-136
-  BCG_TRY(apply_shifted(c, st->g, st->mass, sigma[0], st->T, st->P[0]));
+  // T = (A + sigma_0) P_0 ; alpha_inv = P_0^dagger T                          :134-140
   ++st->iter;                                            // :137
   st->alpha_inv_old = st->alpha_inv;                     // :139
-  BCG_TRY(gram(c, st->P[0], st->T, st->alpha_inv));      // :140   (global reduction #1)
+  BCG_TRY(phase_A(c, st->g, st->mass, sigma[0], st->T, st->P[0], st->alpha_inv));  // global reduction #1
   if (!st->alpha_inv.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "SBCGrQ: P^dagger A P is not finite");
   st->alpha = bcg::inverse_full_pivot(st->alpha_inv);    // :142
   const CMat alpha_delta = st->alpha * st->delta;        // :145 uses delta of the previous iteration
-  // Q -= T alpha                                                             :148
-  BCG_TRY(rmul(c, st->Q, st->T, -st->alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));
+  // Q -= T alpha ; Gram matrix of the new Q                                  :148, :152
+  CMat G2;
+  BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2));      // global reduction #2
   st->rho_old = st->rho;                                 // :150
-  BCG_TRY(thin_qr(c, st->Q, st->rho));                   // :152   (global reduction #2)
+  if (!G2.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not finite");
+  if (!bcg::cholesky_upper(G2, st->rho)) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not positive definite");
   st->delta = st->rho * st->delta;                       // :153
   st->residual = max_ratio(st->delta.row_norms(), st->b_norm);  // :155
-  // X_0 += P_0 (alpha delta_old) -- issued after the QR; it only needs the old P_0   :145
-  BCG_TRY(rmul(c, st->X[0], st->P[0], alpha_delta, 0.0, bcg::RMUL_ADD, "block_axpy"));
-  // P_0 = P_0 rho^dagger + Q                                                 :158
-  BCG_TRY(rmul(c, st->P[0], st->Q, st->rho.adjoint(), 1.0, bcg::RMUL_XPAY, "block_xpay"));
 
   const bool tracing = trace && trace->recorded < trace->capacity;
   double* tm = nullptr;
@@ -803,16 +907,24 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
       for (int s = 0; s < n_shifts; ++s) tr[1 + s] = -1.0;
     }
   }
+  // Coefficients of every active shift (host, m x m), then ONE pass over the fields (phase C):
+  //   Q <- Q rho^{-1} (:152) ; X_0 += P_0 alpha delta_old (:145) ; P_0 <- P_0 rho^dagger + Q (:158)
+  //   X_s += P_s alpha_s (:175) ; P_s <- P_s beta_s rho^dagger + Q (:177)
   const CMat rho_dag = st->rho.adjoint();
-  for (int s = st->n_unconverged - 1; s > 0; --s) {  // :161
+  std::vector<CMat> Acoef(1, alpha_delta), Bcoef(1, rho_dag);
+  std::vector<bcg_field*> Xa(1, st->X[0]), Pa(1, st->P[0]);
+  const int n_active = st->n_unconverged;
+  for (int s = n_active - 1; s > 0; --s) {  // :161
     const CMat beta_s_inv = Identity + (sigma[s] - sigma[0]) * st->alpha +
                             st->alpha * st->rho_old * st->alpha_inv_old * (Identity - st->beta_s[s]) *
                                 st->rho_old.adjoint();                                                   // :163-165
     st->beta_s[s] = bcg::inverse_full_pivot(beta_s_inv);                                                 // :166
     st->alpha_s[s] = st->beta_s[s] * st->alpha * st->rho_old * st->alpha_inv_old * st->alpha_s[s];       // :167-168
     const double residual_shift = max_ratio((st->rho * st->alpha_inv * st->alpha_s[s]).row_norms(), st->b_norm);  // :169-172
-    BCG_TRY(rmul(c, st->X[s], st->P[s], st->alpha_s[s], 0.0, bcg::RMUL_ADD, "block_axpy"));              // :175
-    BCG_TRY(rmul(c, st->P[s], st->Q, st->beta_s[s] * rho_dag, 1.0, bcg::RMUL_XPAY, "block_xpay"));       // :177
+    Acoef.push_back(st->alpha_s[s]);                                                                     // :175
+    Bcoef.push_back(st->beta_s[s] * rho_dag);                                                            // :177
+    Xa.push_back(st->X[s]);
+    Pa.push_back(st->P[s]);
     if (tm) {
       st->alpha_s[s].store(tm + (3 + s) * mm2);
       st->beta_s[s].store(tm + (3 + n_shifts + s) * mm2);
@@ -820,6 +932,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
     if (tr) tr[1 + s] = residual_shift;
     if (residual_shift < st->eps_shifts) --st->n_unconverged;  // :179-181
   }
+  BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef));
   if (tracing) trace->recorded += 1;
   return BCG_OK;
 }

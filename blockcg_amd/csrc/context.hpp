@@ -47,6 +47,7 @@ struct bcg_context {
   bcg_comm comm{};
   bool have_comm = false;
   bool force_generic = false;
+  int hop_c2 = 0;  // x2 chunk of the stencil's cache-blocked traversal (0 = lexicographic)
 
   // scratch
   std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_gram_generic(int64_t rows, const double
       }
       partials[static_cast<int64_t>(blockIdx.x) * P + threadIdx.x] = s;
     }
-  } else {
+  } else if (active) {
 #pragma unroll
     for (int q = 0; q < NPT; ++q) {
       const int p = p0 + q * 256;

@@ -1,0 +1,670 @@
+// MFMA fast path for gfx950 (MI355X): fused SBCGrQ phase kernels for block widths m = 16 and 32
+// (hop kernels also m = 8).  Wave = 64 lanes throughout; no other target is supported.
+//
+// A block field is a tall real matrix of 3V rows x 2m columns, (re,im) interleaved, rows contiguous.
+// The tall-skinny products  out = in * C  (C complex m x m) are done by v_mfma_f64_16x16x4_f64 in
+// the transposed form  out^T (2m x 16 rows) = Cr^T (2m x 2m) * in^T (2m x 16 rows):
+//   - a wave owns a tile of 16 consecutive rows; lane l = (r = l&15, kq = l>>4) holds the complex
+//     elements j = 4s + kq (s = 0..m/4-1) of row r  -> its registers ARE the MFMA B operands
+//     (B[k = l>>4][n = l&15]) with no data movement, and the accumulator fragment
+//     (D[(l>>4) + 4 reg][l&15]) lands in the same (row, column) ownership, so y += x*C, y = y*C + x
+//     chain in registers;
+//   - the coefficient matrix is the A operand, read per MFMA from LDS (one ds_read_b64 per lane).
+//     Cr = [[Re C, Im C], [-Im C, Re C]] is never materialised: the lane reads Re or Im of C(j_in,
+//     j_out) and the minus sign is the MFMA's NEG modifier on A.
+// Block inner products (contraction over rows) need lane = (row = l>>4, column = l&15): the stencil
+// kernel has that ownership natively (lane = (site, rhs)); phase B transposes its 16 x m tile
+// through LDS.  Gram partials are reduced in a fixed order (deterministic).
+//
+// fp64 MFMA and fp64 VALU have the same peak on gfx950; MFMA is used so that the VALU and LDS stay
+// free for addressing and the loads/stores, and the kernels remain HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "kernels_mfma.hpp"
+
+namespace bcg {
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ d4 mfma_nega(double a, double b, d4 c) {  // c + (-a) * b
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
+
+// ---- coefficient matrices in LDS ------------------------------------------------------------------
+// Layout: Ml[j_in * LD + 2*j_out + comp], LD = 2M + 1 doubles (row stride M*16 + 8 bytes keeps the
+// two 16-lane halves of a ds_read_b64 group on disjoint banks).
+template <int M>
+struct MatLds {
+  static constexpr int LD = 2 * M + 1;
+  static constexpr int DOUBLES = M * LD;
+};
+
+// global: complex column-major, element (i,j) at j*M + i.
+template <int M>
+__device__ __forceinline__ void stage_matrix(double* Ml, const double2* __restrict__ Cg, int tid, int nthreads) {
+  for (int e = tid; e < M * M; e += nthreads) {
+    const int i = e % M, jo = e / M;
+    const double2 v = Cg[e];
+    Ml[i * MatLds<M>::LD + 2 * jo] = v.x;
+    Ml[i * MatLds<M>::LD + 2 * jo + 1] = v.y;
+  }
+}
+
+// ---- 16-row tile in (r = l&15, kq = l>>4) ownership -------------------------------------------------
+template <int M>
+struct Tile {
+  double2 v[M / 4];
+};
+
+template <int M>
+__device__ __forceinline__ void tile_load(Tile<M>& t, const double2* __restrict__ f, int64_t row, int kq, bool ok) {
+  const double2* p = f + row * M + kq;
+#pragma unroll
+  for (int s = 0; s < M / 4; ++s) t.v[s] = ok ? p[4 * s] : make_double2(0.0, 0.0);
+}
+template <int M>
+__device__ __forceinline__ void tile_store(const Tile<M>& t, double2* __restrict__ f, int64_t row, int kq, bool ok) {
+  double2* p = f + row * M + kq;
+  if (ok) {
+#pragma unroll
+    for (int s = 0; s < M / 4; ++s) p[4 * s] = t.v[s];
+  }
+}
+
+// accumulator fragments <-> tile.  Output element (s_o, ri_o) of the lane sits in acc[q>>2][q&3],
+// q = ri_o*(M/4) + s_o.
+template <int M>
+struct Acc {
+  d4 a[M / 8];
+};
+template <int M>
+__device__ __forceinline__ void acc_from_tile(Acc<M>& A, const Tile<M>& t) {
+#pragma unroll
+  for (int s = 0; s < M / 4; ++s) {
+    A.a[s >> 2][s & 3] = t.v[s].x;
+    A.a[(M / 4 + s) >> 2][(M / 4 + s) & 3] = t.v[s].y;
+  }
+}
+template <int M>
+__device__ __forceinline__ void acc_zero(Acc<M>& A) {
+#pragma unroll
+  for (int q = 0; q < M / 8; ++q) A.a[q] = d4{0.0, 0.0, 0.0, 0.0};
+}
+template <int M>
+__device__ __forceinline__ void tile_from_acc(Tile<M>& t, const Acc<M>& A) {
+#pragma unroll
+  for (int s = 0; s < M / 4; ++s) {
+    t.v[s].x = A.a[s >> 2][s & 3];
+    t.v[s].y = A.a[(M / 4 + s) >> 2][(M / 4 + s) & 3];
+  }
+}
+
+// acc += in * C   (C staged in LDS at Ml).  M >= 16 (the re/im block of an output tile must not
+// depend on the lane).
+template <int M>
+__device__ __forceinline__ void rmul_acc(Acc<M>& A, const Tile<M>& in, const double* Ml, int lane) {
+  static_assert(M == 16 || M == 32, "MFMA right-multiply is instantiated for m = 16, 32");
+  constexpr int LD = MatLds<M>::LD;
+  const int kq = lane >> 4;          // which of the 4 k-slots of a step this lane feeds (B operand)
+  const int ar = lane & 15;          // A-operand row: output slot dr = kq_o + 4*reg_o
+#pragma unroll
+  for (int T = 0; T < M / 8; ++T) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int ri_o = (4 * T) / (M / 4);                          // lane independent for M >= 16
+    const int s_o = (4 * T + (ar >> 2)) % (M / 4);
+    const int j_o = 4 * s_o + (ar & 3);
+    const double* base = Ml + kq * LD + 2 * j_o;                 // + s_i*4*LD + comp
+#pragma unroll
+    for (int s_i = 0; s_i < M / 4; ++s_i) {
+      const double a_same = base[s_i * 4 * LD + 0 + 0];          // Re C(j_i, j_o)
+      const double a_cross = base[s_i * 4 * LD + 1];             // Im C(j_i, j_o)
+      if (ri_o == 0) {
+        // out_re += in_re * Re C - in_im * Im C
+        A.a[T] = mfma(a_same, in.v[s_i].x, A.a[T]);
+        A.a[T] = mfma_nega(a_cross, in.v[s_i].y, A.a[T]);
+      } else {
+        // out_im += in_re * Im C + in_im * Re C
+        A.a[T] = mfma(a_cross, in.v[s_i].x, A.a[T]);
+        A.a[T] = mfma(a_same, in.v[s_i].y, A.a[T]);
+      }
+    }
+  }
+}
+
+// Two products sharing the B operand (the P_s tile): X += P*Ca and Pn += P*Cb.
+template <int M>
+__device__ __forceinline__ void rmul_acc2(Acc<M>& A1, const double* Ml1, Acc<M>& A2, const double* Ml2, const Tile<M>& in,
+                                          int lane) {
+  constexpr int LD = MatLds<M>::LD;
+  const int kq = lane >> 4;
+  const int ar = lane & 15;
+#pragma unroll
+  for (int T = 0; T < M / 8; ++T) {
+    const int ri_o = (4 * T) / (M / 4);
+    const int s_o = (4 * T + (ar >> 2)) % (M / 4);
+    const int j_o = 4 * s_o + (ar & 3);
+    const int off = kq * LD + 2 * j_o;
+#pragma unroll
+    for (int s_i = 0; s_i < M / 4; ++s_i) {
+      const double a1s = Ml1[off + s_i * 4 * LD], a1c = Ml1[off + s_i * 4 * LD + 1];
+      const double a2s = Ml2[off + s_i * 4 * LD], a2c = Ml2[off + s_i * 4 * LD + 1];
+      if (ri_o == 0) {
+        A1.a[T] = mfma(a1s, in.v[s_i].x, A1.a[T]);
+        A2.a[T] = mfma(a2s, in.v[s_i].x, A2.a[T]);
+        A1.a[T] = mfma_nega(a1c, in.v[s_i].y, A1.a[T]);
+        A2.a[T] = mfma_nega(a2c, in.v[s_i].y, A2.a[T]);
+      } else {
+        A1.a[T] = mfma(a1c, in.v[s_i].x, A1.a[T]);
+        A2.a[T] = mfma(a2c, in.v[s_i].x, A2.a[T]);
+        A1.a[T] = mfma(a1s, in.v[s_i].y, A1.a[T]);
+        A2.a[T] = mfma(a2s, in.v[s_i].y, A2.a[T]);
+      }
+    }
+  }
+}
+
+// ---- Gram accumulation ---------------------------------------------------------------------------
+// Operands in (row k = l>>4, column n = l&15 [+16 jb]) ownership.  Per j-block pair (ja, jb):
+//   re(ja,jb) += a_re*b_re + a_im*b_im ;  im(ja,jb) += a_re*b_im - a_im*b_re      (conj(a) * b)
+template <int M>
+struct GramAcc {
+  d4 re[(M / 16) * (M / 16)];
+  d4 im[(M / 16) * (M / 16)];
+};
+template <int M>
+__device__ __forceinline__ void gram_zero(GramAcc<M>& G) {
+#pragma unroll
+  for (int q = 0; q < (M / 16) * (M / 16); ++q) {
+    G.re[q] = d4{0.0, 0.0, 0.0, 0.0};
+    G.im[q] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+}
+// a[jb], b[jb]: the lane's complex element of column 16*jb + (l&15) for the wave's 4 rows of this step
+template <int M>
+__device__ __forceinline__ void gram_step(GramAcc<M>& G, const double2* a, const double2* b) {
+  constexpr int JB = M / 16;
+#pragma unroll
+  for (int ja = 0; ja < JB; ++ja)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+      const int q = ja * JB + jb;
+      G.re[q] = mfma(a[ja].x, b[jb].x, G.re[q]);
+      G.re[q] = mfma(a[ja].y, b[jb].y, G.re[q]);
+      G.im[q] = mfma(a[ja].x, b[jb].y, G.im[q]);
+      G.im[q] = mfma_nega(a[ja].y, b[jb].x, G.im[q]);
+    }
+}
+
+// Sum the per-wave fragments of a block in wave order and write partials[block][j*M + i].
+// red: LDS scratch of NW * JB*JB * 2 * 4 * 64 doubles.
+template <int M, int NW>
+__device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* red, double2* __restrict__ partials, int tid) {
+  constexpr int JB = M / 16;
+  constexpr int FR = JB * JB * 2 * 4;  // doubles per lane
+  const int wave = tid >> 6, lane = tid & 63;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < JB * JB; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[((wave * FR) + (q * 8 + r)) * 64 + lane] = G.re[q][r];
+      red[((wave * FR) + (q * 8 + 4 + r)) * 64 + lane] = G.im[q][r];
+    }
+  __syncthreads();
+  // element e = (q, r, lane): i = 16*ja + (lane>>4) + 4r, j = 16*jb + (lane&15)
+  for (int e = tid; e < JB * JB * 4 * 64; e += NW * 64) {
+    const int l = e & 63, r = (e >> 6) & 3, q = e >> 8;
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      sr += red[((w * FR) + (q * 8 + r)) * 64 + l];
+      si += red[((w * FR) + (q * 8 + 4 + r)) * 64 + l];
+    }
+    const int i = 16 * (q / JB) + (l >> 4) + 4 * r, j = 16 * (q % JB) + (l & 15);
+    partials[static_cast<int64_t>(blockIdx.x) * (M * M) + j * M + i] = make_double2(sr, si);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Phase B:  Q -= T*alpha  (matrix passed as -alpha),  accumulate Q^dagger Q of the NEW Q.
+// ---------------------------------------------------------------------------------------------------
+template <int M>
+__global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
+                                                const double2* __restrict__ negalpha, double2* __restrict__ partials) {
+  constexpr int NW = 4;
+  constexpr int TLD = M * 2 + 2;  // doubles per transposition row (M*16 + 16 bytes)
+  constexpr int JB = M / 16;
+  constexpr int RED = NW * JB * JB * 8 * 64;
+  constexpr int TRN = NW * 16 * TLD;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ml = smem;                                   // MatLds<M>::DOUBLES
+  double* scratch = smem + ((MatLds<M>::DOUBLES + 1) & ~1);  // max(RED, TRN) doubles, 16-B aligned
+  (void)RED; (void)TRN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(Ml, negalpha, tid, 256);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  double* tw = scratch + wave * 16 * TLD;
+  GramAcc<M> G;
+  gram_zero(G);
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = row < rows;
+    Tile<M> t, q;
+    tile_load<M>(t, T, row, kq, ok);
+    tile_load<M>(q, Q, row, kq, ok);
+    Acc<M> A;
+    acc_from_tile<M>(A, q);
+    rmul_acc<M>(A, t, Ml, lane);
+    tile_from_acc<M>(q, A);
+    tile_store<M>(q, Q, row, kq, ok);
+    // transpose the new tile through LDS: write (r, j = 4s+kq), read (row = 4g + (l>>4), j = l&15 + 16 jb)
+#pragma unroll
+    for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = q.v[s];
+    // same wave wrote and reads: no barrier needed, only LDS ordering (ds ops of one wave are in order)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double2 a[JB];
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+        a[jb] = *reinterpret_cast<const double2*>(tw + (4 * g + (lane >> 4)) * TLD + 2 * (16 * jb + (lane & 15)));
+      gram_step<M>(G, a, a);
+    }
+  }
+  gram_block_store<M, NW>(G, scratch, partials, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Phase C:  Q <- Q*Rinv ; for each active shift s:  X_s += P_s*A_s ;  P_s <- P_s*B_s + Q.
+// mats: [Rinv, A_0, B_0, A_1, B_1, ...] complex column-major, consecutive in device memory.
+// ---------------------------------------------------------------------------------------------------
+struct ShiftPtrs {
+  double2* X[8];
+  double2* P[8];
+};
+
+template <int M>
+__global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
+                                                const double2* __restrict__ mats, int apply_rinv) {
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nmat = 1 + 2 * nshift;
+  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k) * M * M, tid, 256);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = row < rows;
+    Tile<M> q;
+    tile_load<M>(q, Q, row, kq, ok);
+    Tile<M> p, x;
+    if (nshift > 0) {
+      tile_load<M>(p, sp.P[0], row, kq, ok);
+      tile_load<M>(x, sp.X[0], row, kq, ok);
+    }
+    if (apply_rinv) {
+      Acc<M> A;
+      acc_zero<M>(A);
+      rmul_acc<M>(A, q, smem, lane);
+      tile_from_acc<M>(q, A);
+      tile_store<M>(q, Q, row, kq, ok);
+    }
+    for (int s = 0; s < nshift; ++s) {
+      Tile<M> pn, xn;
+      if (s + 1 < nshift) {  // prefetch the next shift's tiles while this one computes
+        tile_load<M>(pn, sp.P[s + 1], row, kq, ok);
+        tile_load<M>(xn, sp.X[s + 1], row, kq, ok);
+      }
+      Acc<M> AX, AP;
+      acc_from_tile<M>(AX, x);
+      acc_from_tile<M>(AP, q);
+      rmul_acc2<M>(AX, smem + (1 + 2 * s) * MD, AP, smem + (2 + 2 * s) * MD, p, lane);
+      tile_from_acc<M>(x, AX);
+      tile_store<M>(x, sp.X[s], row, kq, ok);
+      tile_from_acc<M>(p, AP);
+      tile_store<M>(p, sp.P[s], row, kq, ok);
+      if (s + 1 < nshift) {
+        p = pn;
+        x = xn;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stand-alone right-multiplications (K5, K6) on the MFMA path, for the field-level API.
+// ---------------------------------------------------------------------------------------------------
+template <int M, int MODE>
+__global__ void __launch_bounds__(256) k_rmul_mfma(int64_t rows, double2* __restrict__ y, const double2* __restrict__ x,
+                                                   const double2* __restrict__ Cg, double b) {
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(smem, Cg, tid, 256);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = row < rows;
+    Tile<M> ty, tx;
+    tile_load<M>(ty, y, row, kq, ok);
+    Acc<M> A;
+    if (MODE == RMUL_ADD) {          // y += x*C
+      tile_load<M>(tx, x, row, kq, ok);
+      acc_from_tile<M>(A, ty);
+      rmul_acc<M>(A, tx, smem, lane);
+    } else if (MODE == RMUL_XPAY) {  // y = y*C + b*x
+      tile_load<M>(tx, x, row, kq, ok);
+#pragma unroll
+      for (int s = 0; s < M / 4; ++s) tx.v[s] = make_double2(b * tx.v[s].x, b * tx.v[s].y);
+      acc_from_tile<M>(A, tx);
+      rmul_acc<M>(A, ty, smem, lane);
+    } else {                         // y = y*C
+      acc_zero<M>(A);
+      rmul_acc<M>(A, ty, smem, lane);
+    }
+    tile_from_acc<M>(ty, A);
+    tile_store<M>(ty, y, row, kq, ok);
+  }
+}
+
+// Stand-alone Gram product a^dagger b: coalesced loads already have (row = l>>4, col = l&15) ownership.
+template <int M>
+__global__ void __launch_bounds__(256) k_gram_mfma(int64_t rows, const double2* __restrict__ a, const double2* __restrict__ b,
+                                                   double2* __restrict__ partials) {
+  constexpr int NW = 4;
+  constexpr int JB = M / 16;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  GramAcc<M> G;
+  gram_zero(G);
+  const int64_t nquads = (rows + 3) / 4;  // 4 rows per MFMA step
+  for (int64_t qd = static_cast<int64_t>(blockIdx.x) * NW + wave; qd < nquads; qd += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = qd * 4 + (lane >> 4);
+    const bool ok = row < rows;
+    double2 av[JB], bv[JB];
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+      av[jb] = ok ? a[row * M + 16 * jb + (lane & 15)] : make_double2(0.0, 0.0);
+      bv[jb] = ok ? b[row * M + 16 * jb + (lane & 15)] : make_double2(0.0, 0.0);
+    }
+    gram_step<M>(G, av, bv);
+  }
+  gram_block_store<M, NW>(G, smem, partials, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stencil (K1) fast path.  Block = 256 threads = 4 waves; wave = 64/M sites x M right-hand sides,
+// lane = (site, j).  The 2*ndim links of the block's sites are staged once per tile in LDS by one
+// thread per link (144 contiguous bytes) and then read as LDS broadcasts, instead of every lane
+// fetching every link from global memory.  Blocks walk the lattice in tiles of SPB consecutive x0
+// sites; with c2 > 0 the walk is blocked in x2 (chunks of c2 planes, x3 inside) so that the three
+// x3-slices a chunk needs stay resident in the 256 MiB Infinity Cache.
+// MODE HOP_SHIFTED: out = c0*p - D in; with GRAM (m = 16) also accumulates p^dagger out.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void coords_of(const LatticeDev& lat, int64_t site, int x[4]) {
+  x[0] = static_cast<int>(site % lat.L[0]); site /= lat.L[0];
+  x[1] = static_cast<int>(site % lat.L[1]); site /= lat.L[1];
+  x[2] = static_cast<int>(site % lat.L[2]); site /= lat.L[2];
+  x[3] = static_cast<int>(site);
+}
+__device__ __forceinline__ int64_t face_idx(const LatticeDev& lat, const int x[4], int mu) {
+  int64_t f = 0, st = 1;
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) {
+    if (nu == mu) continue;
+    f += x[nu] * st;
+    st *= lat.L[nu];
+  }
+  return f;
+}
+
+template <int M, int MODE, bool GRAM>
+__global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2* __restrict__ U,
+                                                  const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                                  const double2* __restrict__ ghost, double2* __restrict__ out,
+                                                  const double2* __restrict__ p, double c0,
+                                                  double2* __restrict__ partials, int64_t ntiles, int c2) {
+  static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  constexpr int SPW = 64 / M;
+  constexpr int SPB = 4 * SPW;
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double2* Us = reinterpret_cast<double2*>(smem);  // [SPB][4 mu][2 dir][9]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sl = wave * SPW + lane / M;
+  const int j = lane % M;
+  GramAcc<16> G;
+  if (GRAM) gram_zero(G);
+  const int tiles_x0 = lat.L[0] / SPB;  // used only when c2 > 0 (host guarantees divisibility)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t site0;
+    if (c2 > 0) {
+      int64_t t = tile;
+      const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
+      const int x1 = static_cast<int>(t % lat.L[1]); t /= lat.L[1];
+      const int x2l = static_cast<int>(t % c2); t /= c2;
+      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
+      const int x2 = static_cast<int>(t) * c2 + x2l;
+      site0 = a * SPB + x1 * lat.stride[1] + x2 * lat.stride[2] + x3 * lat.stride[3];
+    } else {
+      site0 = tile * SPB;
+    }
+    __syncthreads();
+    // ---- stage links: thread e = (site s, mu, dir) copies one 3x3 link
+    if (tid < SPB * lat.ndim * 2) {
+      const int dir = tid & 1;
+      const int mu = (tid >> 1) % lat.ndim;
+      const int s = (tid >> 1) / lat.ndim;
+      const int64_t site = site0 + s;
+      if (site < lat.V) {
+        const double2* src;
+        if (dir == 0) {
+          src = U + (site * lat.ndim + mu) * 9;
+        } else {
+          int x[4];
+          coords_of(lat, site, x);
+          if (x[mu] > 0) src = U + ((site - lat.stride[mu]) * lat.ndim + mu) * 9;
+          else if (!lat.split[mu]) src = U + ((site + (lat.L[mu] - 1) * lat.stride[mu]) * lat.ndim + mu) * 9;
+          else src = Ughost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 9;
+        }
+        double2* dst = Us + ((s * 4 + mu) * 2 + dir) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = src[k];
+      }
+    }
+    __syncthreads();
+    // ---- compute
+    const int64_t site = site0 + sl;
+    const bool ok = site < lat.V;
+    double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+    if (ok) {
+      int x[4];
+      coords_of(lat, site, x);
+      int parity = 0;
+      for (int mu = 0; mu < lat.ndim; ++mu) {
+        const double eta = (parity & 1) ? -1.0 : 1.0;
+        const double2* pf;
+        if (x[mu] + 1 < lat.L[mu]) pf = in + (site + lat.stride[mu]) * 3 * M;
+        else if (!lat.split[mu]) pf = in + (site - (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
+        else pf = ghost + (lat.ghost_off[mu][1] + face_idx(lat, x, mu)) * 3 * M;
+        const double2* pb;
+        if (x[mu] > 0) pb = in + (site - lat.stride[mu]) * 3 * M;
+        else if (!lat.split[mu]) pb = in + (site + (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
+        else pb = ghost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 3 * M;
+        double2 f[3], bk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          f[k] = pf[k * M + j];
+          bk[k] = pb[k * M + j];
+        }
+        const double2* uf = Us + ((sl * 4 + mu) * 2 + 0) * 9;
+        const double2* ub = Us + ((sl * 4 + mu) * 2 + 1) * 9;
+        double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const double2 u = uf[k * 3 + r];   // U(r,k)
+            t[r].x = fma(u.x, f[k].x, t[r].x); t[r].x = fma(-u.y, f[k].y, t[r].x);
+            t[r].y = fma(u.x, f[k].y, t[r].y); t[r].y = fma(u.y, f[k].x, t[r].y);
+            const double2 v = ub[r * 3 + k];   // U_b(k,r); subtract conj(v) * psi_b(k)
+            t[r].x = fma(-v.x, bk[k].x, t[r].x); t[r].x = fma(-v.y, bk[k].y, t[r].x);
+            t[r].y = fma(-v.x, bk[k].y, t[r].y); t[r].y = fma(v.y, bk[k].x, t[r].y);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          acc[r].x = fma(eta, t[r].x, acc[r].x);
+          acc[r].y = fma(eta, t[r].y, acc[r].y);
+        }
+        parity += x[mu] + lat.origin[mu];
+      }
+    }
+    double2 pv[3], tv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int64_t o = (site * 3 + r) * M + j;
+      if (MODE == HOP_PLAIN) {
+        tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+        if (ok) out[o] = tv[r];
+      } else {
+        pv[r] = ok ? p[o] : make_double2(0.0, 0.0);
+        tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+        if (ok) out[o] = tv[r];
+        else tv[r] = make_double2(0.0, 0.0);
+      }
+    }
+    if (GRAM) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
+    }
+  }
+  if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
+}
+
+inline int grid_tiles(int64_t ntiles, int per_block, int cap) {
+  int64_t g = (ntiles + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return static_cast<int>(g);
+}
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
+}  // namespace
+
+bool mfma_width(int m) { return m == 16 || m == 32; }  // declared in kernels.hpp
+bool hop_fast_width(int m) { return m == 8 || m == 16 || m == 32; }
+int phaseC_max_shifts(int m) { return m == 16 ? 8 : (m == 32 ? 1 : 0); }
+
+int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
+                  double2* partials, int max_blocks) {
+  const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
+  if (m == 16) {
+    constexpr int M = 16;
+    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+  } else {
+    constexpr int M = 32;
+    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 4 * 8 * 64);  // RED 8192 >= TRN 4*16*66
+    allow_lds(k_phaseB<M>, lds);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+  }
+  return grid;
+}
+
+void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
+                   const double2* mats, int apply_rinv, int max_blocks) {
+  ShiftPtrs sp{};
+  for (int k = 0; k < nshift && k < 8; ++k) {
+    sp.X[k] = X[k];
+    sp.P[k] = P[k];
+  }
+  const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
+  const int nmat = 1 + 2 * nshift;
+  if (m == 16) {
+    constexpr int M = 16;
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
+    allow_lds(k_phaseC<M>, lds);
+    hipLaunchKernelGGL((k_phaseC<M>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+  } else {
+    constexpr int M = 32;
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
+    allow_lds(k_phaseC<M>, lds);
+    hipLaunchKernelGGL((k_phaseC<M>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+  }
+}
+
+void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
+                      RmulMode mode, int max_blocks) {
+  const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
+#define BCG_RMUL(MM)                                                                                             \
+  {                                                                                                              \
+    constexpr int M = MM;                                                                                        \
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1);                                         \
+    if (mode == RMUL_ADD) hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_ADD>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b);       \
+    else if (mode == RMUL_XPAY) hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_XPAY>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b); \
+    else hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_MUL>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b);       \
+  }
+  if (m == 16) BCG_RMUL(16) else BCG_RMUL(32)
+#undef BCG_RMUL
+}
+
+int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
+                     int max_blocks) {
+  const int grid = grid_tiles((rows + 3) / 4, 4 * 16, max_blocks);
+  if (m == 16) {
+    const size_t lds = sizeof(double) * 4 * 8 * 64;
+    hipLaunchKernelGGL((k_gram_mfma<16>), dim3(grid), dim3(256), lds, s, rows, a, b, partials);
+  } else {
+    const size_t lds = sizeof(double) * 4 * 4 * 8 * 64;
+    allow_lds(k_gram_mfma<32>, lds);
+    hipLaunchKernelGGL((k_gram_mfma<32>), dim3(grid), dim3(256), lds, s, rows, a, b, partials);
+  }
+  return grid;
+}
+
+int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
+                    const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
+                    double2* partials, bool gram, int max_blocks, int c2) {
+  const int spb = 4 * (64 / m);
+  if (c2 > 0 && (lat.ndim != 4 || lat.L[0] % spb != 0 || lat.L[2] % c2 != 0)) c2 = 0;
+  const int64_t ntiles = c2 > 0 ? lat.V / spb : (lat.V + spb - 1) / spb;
+  const int grid = grid_tiles(ntiles, 1, max_blocks);
+  const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;
+  const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
+  const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+#define BCG_HOP(MM)                                                                                                         \
+  {                                                                                                                         \
+    if (mode == HOP_PLAIN)                                                                                                  \
+      hipLaunchKernelGGL((k_hop_fast<MM, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
+                         p, c0, partials, ntiles, c2);                                                                      \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_hop_fast<MM, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost,    \
+                         out, p, c0, partials, ntiles, c2);                                                                 \
+  }
+  if (gram && m == 16 && mode == HOP_SHIFTED) {
+    hipLaunchKernelGGL((k_hop_fast<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out,
+                       p, c0, partials, ntiles, c2);
+  } else if (m == 8) BCG_HOP(8) else if (m == 16) BCG_HOP(16) else BCG_HOP(32)
+#undef BCG_HOP
+  return grid;
+}
+
+}  // namespace bcg

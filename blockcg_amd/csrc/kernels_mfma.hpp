@@ -1,0 +1,29 @@
+// Launchers of the MFMA fast path (kernels_mfma.hip); see that file for the data ownership scheme.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace bcg {
+
+bool hop_fast_width(int m);     // widths served by the LDS-staged stencil kernel (8, 16, 32)
+int phaseC_max_shifts(int m);   // shifts one phase-C launch can take (LDS budget)
+
+// Phase B: Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
+int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
+                  double2* partials, int max_blocks);
+// Phase C: if apply_rinv Q <- Q*mats[0]; for k < nshift: X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + Q.
+void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
+                   const double2* mats, int apply_rinv, int max_blocks);
+void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
+                      RmulMode mode, int max_blocks);
+int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
+                     int max_blocks);
+// Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.
+int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
+                    const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
+                    double2* partials, bool gram, int max_blocks, int c2);
+
+}  // namespace bcg

@@ -212,3 +212,51 @@ def test_error_behaviour(bc):
     assert e.value.code == 6
     # non-convergence = return value equals max_iterations
     assert bc.SBCGrQ(X, B, D, [0.0, 0.1], 1e-300, 1e-300, max_iterations=3) == 3
+
+
+@pytest.mark.parametrize("m", [16, 32, 8])
+@pytest.mark.parametrize("dims", [[5, 3, 7], [16, 4, 4, 6], [37]])
+def test_mfma_fast_path_matches_generic_and_oracle(bc, orc, m, dims):
+    """Fused MFMA kernels against the generic VALU kernels and the oracle, including volumes whose row
+    count is not a multiple of the 16-row MFMA tile and the cache-blocked stencil walk."""
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 31)
+    Bh = orc.fill_field(m, V, 32)
+    Yh = orc.fill_field(m, V, 33)
+    rng = np.random.default_rng(m)
+    M = rng.uniform(-1, 1, (m, m)) + 1j * rng.uniform(-1, 1, (m, m))
+    results = {}
+    for mode in ("fast", "generic"):
+        ctx = bc.Context(dims)
+        ctx.force_generic(mode == "generic")
+        D = bc.dirac_op(ctx, 0.1, U=U)
+        F = lambda a: bc.block_fermion_field(ctx, m, a)  # noqa: E731
+        out = bc.block_fermion_field(ctx, m)
+        D.op(out, F(Bh))
+        hop = bc.block_fermion_field(ctx, m)
+        D.D(hop, F(Bh))
+        q = F(Yh)
+        R = q.thinQR()
+        results[mode] = dict(op=out.download(), hop=hop.download(), add=F(Yh).add(F(Bh), M).download(),
+                             xpay=F(Yh).rescale_add(M, F(Bh), 0.7).download(), dot=F(Yh).hermitian_dot(F(Bh)),
+                             Q=q.download(), R=R)
+    oracle_vals = dict(op=orc.dirac_apply(U, dims, 0.1, Bh), hop=orc.hop(U, dims, Bh), add=orc.add_matrix(Yh, Bh, M),
+                       xpay=orc.rescale_add_matrix(Yh, M, Bh, 0.7), dot=orc.hermitian_dot(Yh, Bh))
+    oracle_vals["Q"], oracle_vals["R"] = orc.thin_qr(Yh)
+    for k, v in oracle_vals.items():
+        assert rel_err(results["fast"][k], v) < 2e-13, ("fast", k)
+        assert rel_err(results["generic"][k], v) < 2e-13, ("generic", k)
+
+
+@pytest.mark.parametrize("c2", ["0", "2"])
+def test_cache_blocked_stencil_walk(bc, orc, c2, monkeypatch):
+    monkeypatch.setenv("BCG_HOP_C2", c2)
+    dims, m = [16, 4, 4, 6], 16
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 41)
+    Bh = orc.fill_field(m, V, 42)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, 0.2, U=U)
+    out = bc.block_fermion_field(ctx, m)
+    D.op(out, bc.block_fermion_field(ctx, m, Bh))
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.2, Bh)) < TOL_KERNEL
