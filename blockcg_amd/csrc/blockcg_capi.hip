@@ -275,7 +275,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     if (gram) BCG_TRY(ensure_scratch(c));
     ProfScope ps(c, gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted"));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, hop_c2_for(c, m));
+                                        p ? p->d : nullptr, c0, c->partials, gram, c->hop_blocks, hop_c2_for(c, m), c->hop_walk);
     if (gram) *gram_blocks = nb;
   } else {
     ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
@@ -519,6 +519,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   c->ghost_sites = ghost;
   c->hop_c2 = -1;
   if (const char* e = std::getenv("BCG_HOP_C2")) c->hop_c2 = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_walk = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_blocks = std::atoi(e);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {

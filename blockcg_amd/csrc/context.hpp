@@ -47,7 +47,9 @@ struct bcg_context {
   bcg_comm comm{};
   bool have_comm = false;
   bool force_generic = false;
-  int hop_c2 = 0;  // x2 chunk of the stencil's cache-blocked traversal (0 = lexicographic)
+  int hop_c2 = -1;      // x2 chunk of the stencil's cache-blocked walk (-1 = auto, 0 = off)
+  int hop_walk = 2;     // 0 lexicographic, 1 x2-chunked, 2 XCD-aware strips (kernels_mfma.hip)
+  int hop_blocks = 768; // persistent grid of the stencil kernel: 3 blocks per CU at its register budget
 
   // scratch
   std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
                                                   const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                                   const double2* __restrict__ ghost, double2* __restrict__ out,
                                                   const double2* __restrict__ p, double c0,
-                                                  double2* __restrict__ partials, int64_t ntiles, int c2) {
+                                                  double2* __restrict__ partials, int64_t ntiles, int c2, int walk) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
@@ -448,11 +448,35 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
   const int j = lane % M;
   GramAcc<16> G;
   if (GRAM) gram_zero(G);
-  const int tiles_x0 = lat.L[0] / SPB;  // used only when c2 > 0 (host guarantees divisibility)
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Tile walk (performance only; every tile is visited exactly once in all three):
+  //  walk 0: block b takes tiles b, b+grid, ...  in lexicographic order.
+  //  walk 1: same, but lexicographic order is blocked in x2 (chunks of c2 planes, x3 inside a chunk).
+  //  walk 2: XCD-aware.  Blocks b and b+8 share an XCD and its 4 MiB L2 (round-robin dispatch), so the
+  //          8 block classes b%8 each own a strip of L1/8 x1-rows; all classes sweep the same x2 chunk
+  //          and x3 slice together.  x0/x1/x2 neighbours are then re-used out of the XCD's own L2 and
+  //          the +-x3 slices of the chunk out of the Infinity Cache.
+  const int tiles_x0 = lat.L[0] / SPB;  // walks 1, 2: host guarantees divisibility
+  int64_t first = blockIdx.x, step = gridDim.x, count = ntiles;
+  int xcd = 0, w1 = 0;
+  if (walk == 2) {
+    xcd = blockIdx.x & 7;
+    first = blockIdx.x >> 3;
+    step = gridDim.x >> 3;
+    count = ntiles >> 3;
+    w1 = lat.L[1] >> 3;
+  }
+  for (int64_t pos = first; pos < count; pos += step) {
     int64_t site0;
-    if (c2 > 0) {
-      int64_t t = tile;
+    if (walk == 2) {
+      int64_t t = pos;
+      const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
+      const int x1 = xcd * w1 + static_cast<int>(t % w1); t /= w1;
+      const int x2l = static_cast<int>(t % c2); t /= c2;
+      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
+      const int x2 = static_cast<int>(t) * c2 + x2l;
+      site0 = a * SPB + x1 * lat.stride[1] + x2 * lat.stride[2] + x3 * lat.stride[3];
+    } else if (walk == 1) {
+      int64_t t = pos;
       const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
       const int x1 = static_cast<int>(t % lat.L[1]); t /= lat.L[1];
       const int x2l = static_cast<int>(t % c2); t /= c2;
@@ -460,7 +484,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
       const int x2 = static_cast<int>(t) * c2 + x2l;
       site0 = a * SPB + x1 * lat.stride[1] + x2 * lat.stride[2] + x3 * lat.stride[3];
     } else {
-      site0 = tile * SPB;
+      site0 = pos * SPB;
     }
     __syncthreads();
     // ---- stage links: thread e = (site s, mu, dir) copies one 3x3 link
@@ -642,11 +666,17 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, int c2) {
+                    double2* partials, bool gram, int max_blocks, int c2, int walk) {
   const int spb = 4 * (64 / m);
-  if (c2 > 0 && (lat.ndim != 4 || lat.L[0] % spb != 0 || lat.L[2] % c2 != 0)) c2 = 0;
-  const int64_t ntiles = c2 > 0 ? lat.V / spb : (lat.V + spb - 1) / spb;
-  const int grid = grid_tiles(ntiles, 1, max_blocks);
+  const bool blockable = lat.ndim == 4 && lat.L[0] % spb == 0 && c2 > 0 && lat.L[2] % c2 == 0;
+  if (walk == 2 && !(blockable && lat.L[1] % 8 == 0 && max_blocks % 8 == 0)) walk = blockable ? 1 : 0;
+  if (walk == 1 && !blockable) walk = 0;
+  const int64_t ntiles = walk > 0 ? lat.V / spb : (lat.V + spb - 1) / spb;
+  int grid = grid_tiles(ntiles, 1, max_blocks);
+  if (walk == 2) {
+    grid &= ~7;
+    if (grid < 8) { walk = 1; grid = grid_tiles(ntiles, 1, max_blocks); }
+  }
   const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
@@ -654,14 +684,14 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
   {                                                                                                                         \
     if (mode == HOP_PLAIN)                                                                                                  \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
-                         p, c0, partials, ntiles, c2);                                                                      \
+                         p, c0, partials, ntiles, c2, walk);                                                                \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost,    \
-                         out, p, c0, partials, ntiles, c2);                                                                 \
+                         out, p, c0, partials, ntiles, c2, walk);                                                           \
   }
   if (gram && m == 16 && mode == HOP_SHIFTED) {
     hipLaunchKernelGGL((k_hop_fast<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out,
-                       p, c0, partials, ntiles, c2);
+                       p, c0, partials, ntiles, c2, walk);
   } else if (m == 8) BCG_HOP(8) else if (m == 16) BCG_HOP(16) else BCG_HOP(32)
 #undef BCG_HOP
   return grid;
