@@ -275,7 +275,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     if (gram) BCG_TRY(ensure_scratch(c));
     ProfScope ps(c, gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted"));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                        p ? p->d : nullptr, c0, c->partials, gram, c->hop_blocks, hop_c2_for(c, m), c->hop_walk);
+                                        p ? p->d : nullptr, c0, c->partials, gram, c->hop_blocks, hop_c2_for(c, m), c->hop_walk, c->hop_flags, c->hop_patch[0], c->hop_patch[1], c->hop_patch[2]);
     if (gram) *gram_blocks = nb;
   } else {
     ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
@@ -521,6 +521,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_C2")) c->hop_c2 = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_blocks = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_flags = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_patch[0], &c->hop_patch[1], &c->hop_patch[2]);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {

@@ -28,12 +28,24 @@ namespace bcg {
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double dv2 __attribute__((ext_vector_type(2)));  // native vector: promotes to registers where HIP's double2 struct does not
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ d4 mfma_nega(double a, double b, d4 c) {  // c + (-a) * b
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
+
+__device__ __forceinline__ double2 ld_nt(const double2* p) {
+  const dv2 v = __builtin_nontemporal_load(reinterpret_cast<const dv2*>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st_nt(double2* p, double2 v) {
+  dv2 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(p));
 }
 
 // ---- coefficient matrices in LDS ------------------------------------------------------------------
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
                                                   const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                                   const double2* __restrict__ ghost, double2* __restrict__ out,
                                                   const double2* __restrict__ p, double c0,
-                                                  double2* __restrict__ partials, int64_t ntiles, int c2, int walk) {
+                                                  double2* __restrict__ partials, int64_t ntiles, int c2, int walk, int flags, int p0, int p1, int p2) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
@@ -458,16 +470,31 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
   const int tiles_x0 = lat.L[0] / SPB;  // walks 1, 2: host guarantees divisibility
   int64_t first = blockIdx.x, step = gridDim.x, count = ntiles;
   int xcd = 0, w1 = 0;
-  if (walk == 2) {
+  //  walk 3: XCD-aware patches.  Each block class b%8 sweeps x3 over a compact patch of p0 x p1 x p2 sites in
+  //          (x0,x1,x2), then takes the next patch; three x3-slices of a patch fit the XCD's L2, so all
+  //          eight neighbour directions are re-used from L2 and only the patch surface is re-fetched.
+  if (walk == 2 || walk == 3) {
     xcd = blockIdx.x & 7;
     first = blockIdx.x >> 3;
     step = gridDim.x >> 3;
     count = ntiles >> 3;
     w1 = lat.L[1] >> 3;
   }
+  const int pt0 = p0 / SPB;                 // tiles along x0 in a patch
+  const int tp = pt0 * p1 * p2;             // tiles per patch slice
+  const int np0 = walk == 3 ? lat.L[0] / p0 : 1, np1 = walk == 3 ? lat.L[1] / p1 : 1;
   for (int64_t pos = first; pos < count; pos += step) {
     int64_t site0;
-    if (walk == 2) {
+    if (walk == 3) {
+      int64_t t = pos;
+      const int q = static_cast<int>(t % tp); t /= tp;
+      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
+      const int64_t patch = t * 8 + xcd;
+      const int pa = static_cast<int>(patch % np0), pb = static_cast<int>((patch / np0) % np1);
+      const int pc = static_cast<int>(patch / (static_cast<int64_t>(np0) * np1));
+      const int a = q % pt0, x1l = (q / pt0) % p1, x2l = q / (pt0 * p1);
+      site0 = (pa * p0 + a * SPB) + (pb * p1 + x1l) * lat.stride[1] + (pc * p2 + x2l) * lat.stride[2] + x3 * lat.stride[3];
+    } else if (walk == 2) {
       int64_t t = pos;
       const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
       const int x1 = xcd * w1 + static_cast<int>(t % w1); t /= w1;
@@ -488,7 +515,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
     }
     __syncthreads();
     // ---- stage links: thread e = (site s, mu, dir) copies one 3x3 link
-    if (tid < SPB * lat.ndim * 2) {
+    if (tid < SPB * lat.ndim * 2 && !((flags & 32) && pos != first)) {  // flag 32: ablation, stage links once
       const int dir = tid & 1;
       const int mu = (tid >> 1) % lat.ndim;
       const int s = (tid >> 1) / lat.ndim;
@@ -505,8 +532,13 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
           else src = Ughost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 9;
         }
         double2* dst = Us + ((s * 4 + mu) * 2 + dir) * 9;
+        if (flags & 4) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dst[k] = src[k];
+          for (int k = 0; k < 9; ++k) dst[k] = ld_nt(src + k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) dst[k] = src[k];
+        }
       }
     }
     __syncthreads();
@@ -528,11 +560,23 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
         if (x[mu] > 0) pb = in + (site - lat.stride[mu]) * 3 * M;
         else if (!lat.split[mu]) pb = in + (site + (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
         else pb = ghost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 3 * M;
+        if (flags & 16) {  // ablation: perfect locality, every neighbour is the site itself
+          pf = in + site * 3 * M;
+          pb = pf;
+        }
         double2 f[3], bk[3];
+        if ((flags & 2) && mu == 3) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          f[k] = pf[k * M + j];
-          bk[k] = pb[k * M + j];
+          for (int k = 0; k < 3; ++k) {
+            f[k] = ld_nt(pf + k * M + j);
+            bk[k] = ld_nt(pb + k * M + j);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            f[k] = pf[k * M + j];
+            bk[k] = pb[k * M + j];
+          }
         }
         const double2* uf = Us + ((sl * 4 + mu) * 2 + 0) * 9;
         const double2* ub = Us + ((sl * 4 + mu) * 2 + 1) * 9;
@@ -563,12 +607,19 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
       const int64_t o = (site * 3 + r) * M + j;
       if (MODE == HOP_PLAIN) {
         tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
-        if (ok) out[o] = tv[r];
+        if (ok) {
+          if (flags & 1) st_nt(out + o, tv[r]);
+          else out[o] = tv[r];
+        }
       } else {
-        pv[r] = ok ? p[o] : make_double2(0.0, 0.0);
+        pv[r] = ok ? ((flags & 8) ? ld_nt(p + o) : p[o]) : make_double2(0.0, 0.0);
         tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-        if (ok) out[o] = tv[r];
-        else tv[r] = make_double2(0.0, 0.0);
+        if (ok) {
+          if (flags & 1) st_nt(out + o, tv[r]);
+          else out[o] = tv[r];
+        } else {
+          tv[r] = make_double2(0.0, 0.0);
+        }
       }
     }
     if (GRAM) {
@@ -576,6 +627,289 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
       for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
     }
   }
+  if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stencil, specialised: ndim = 4, L0 a multiple of the tile (SPB consecutive x0 sites), local volume
+// < 2^31 sites.  Everything that is uniform over a tile -- its coordinates, the six x1/x2/x3
+// neighbour tiles, their ghost redirection, the staggered phases -- is scalar work done once per tile
+// in 32-bit arithmetic; only the +-x0 neighbours need per-lane selects.  The 2*4 links of the tile's
+// sites are fetched one tile ahead by all 256 threads (forward links of a tile are one contiguous 9 KB
+// run; U_0(x-0) is the forward link of the previous site), parked in registers during the compute of
+// the current tile and written to the other half of a double-buffered LDS image: one barrier per tile.
+// ---------------------------------------------------------------------------------------------------
+struct TileGeom {
+  int x0b, x1, x2, x3;   // coordinates of the tile's first site
+  int site0;             // its local site index
+};
+
+// Tile order: mixed-radix counter, fastest digit first:
+//   (x0 tile in patch, x1 in patch, x2 in patch, x3, patch x0, patch x1, patch x2)
+// Lexicographic order is the special case patch = whole (x0,x1,x2) volume.  With xcd_split the
+// sequence is cut into 8 contiguous ranges, one per block class b%8 (blocks b and b+8 share an XCD
+// and its L2 under round-robin dispatch): each XCD sweeps x3 over one compact patch at a time, so
+// three x3-slices of a patch can live in its 4 MiB L2.  Performance only: every tile is visited once.
+struct HopWalk {
+  int p0, p1, p2;        // patch extents (sites) in x0, x1, x2
+  int xcd_split;
+};
+
+struct Digits {
+  int d0, d1, d2, d3, d4, d5, d6;
+};
+
+__device__ __forceinline__ Digits digits_of(unsigned v, int r0, int r1, int r2, int r3, int r4, int r5) {
+  Digits g;
+  g.d0 = v % r0; v /= r0;
+  g.d1 = v % r1; v /= r1;
+  g.d2 = v % r2; v /= r2;
+  g.d3 = v % r3; v /= r3;
+  g.d4 = v % r4; v /= r4;
+  g.d5 = v % r5; v /= r5;
+  g.d6 = v;
+  return g;
+}
+#define BCG_ADD_DIGIT(D, S, R)            \
+  {                                       \
+    D += S + carry;                       \
+    carry = 0;                            \
+    if (D >= R) { D -= R; carry = 1; }    \
+  }
+__device__ __forceinline__ void digits_add(Digits& a, const Digits& s, int r0, int r1, int r2, int r3, int r4, int r5) {
+  int carry = 0;
+  BCG_ADD_DIGIT(a.d0, s.d0, r0)
+  BCG_ADD_DIGIT(a.d1, s.d1, r1)
+  BCG_ADD_DIGIT(a.d2, s.d2, r2)
+  BCG_ADD_DIGIT(a.d3, s.d3, r3)
+  BCG_ADD_DIGIT(a.d4, s.d4, r4)
+  BCG_ADD_DIGIT(a.d5, s.d5, r5)
+  a.d6 += s.d6 + carry;
+}
+#undef BCG_ADD_DIGIT
+
+template <int SPB>
+__device__ __forceinline__ TileGeom geom_of(const Digits& d, int r0, int p1, int p2, int L0, int L1, int L2) {
+  TileGeom g;
+  g.x0b = (d.d4 * r0 + d.d0) * SPB;
+  g.x1 = d.d5 * p1 + d.d1;
+  g.x2 = d.d6 * p2 + d.d2;
+  g.x3 = d.d3;
+  g.site0 = g.x0b + L0 * (g.x1 + L1 * (g.x2 + L2 * g.x3));
+  return g;
+}
+
+// Forward links of a tile: SPB*36 contiguous complex numbers, coalesced over the 256 threads.
+template <int SPB, int RF>
+__device__ __forceinline__ void fetch_fwd(const double2* __restrict__ fsrc, int tid, dv2 (&rf)[RF]) {
+#pragma unroll
+  for (int k = 0; k < RF; ++k) {
+    const int e = tid + 256 * k;
+    if (e < SPB * 36) rf[k] = *reinterpret_cast<const dv2*>(fsrc + e);
+  }
+}
+
+// Backward links U_mu(x - mu) of one direction mu >= 1 for the tile's SPB sites (compile-time mu: a
+// run-time mu would make the compiler index a scratch copy of the geometry).  Thread t < SPB*9 (+256 k)
+// fetches element c9 of site s.
+template <int SPB, int RBM>
+__device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int spm, int64_t gm, int fi0, int site0,
+                                           const double2* __restrict__ U, const double2* __restrict__ Ughost, int tid,
+                                           dv2 (&rb)[RBM]) {
+#pragma unroll
+  for (int k = 0; k < RBM; ++k) {
+    const int e = tid + 256 * k;
+    if (e < SPB * 9) {
+      const int s = e / 9, c9 = e - s * 9;
+      const double2* src;
+      if (xm > 0) src = U + ((static_cast<int64_t>(site0) + s - Sm) * 4 + mu) * 9;
+      else if (!spm) src = U + ((static_cast<int64_t>(site0) + s + static_cast<int64_t>(Lm - 1) * Sm) * 4 + mu) * 9;
+      else src = Ughost + (gm + fi0 + s) * 9;
+      rb[k] = *reinterpret_cast<const dv2*>(src + c9);
+    }
+  }
+}
+
+template <int M, int MODE, bool GRAM>
+__global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
+                                              const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                              const double2* __restrict__ ghost, double2* __restrict__ out,
+                                              const double2* __restrict__ p, double c0,
+                                              double2* __restrict__ partials, int ntiles, HopWalk hw, int flags) {
+  static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  (void)flags;  // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
+  constexpr int SPW = 64 / M;
+  constexpr int SPB = 4 * SPW;
+  constexpr int NW = 4;
+  constexpr int NF = (SPB + 1) * 36;   // forward links of sites -1 .. SPB-1 (all 4 directions)
+  constexpr int NB = 3 * SPB * 9;      // backward links of directions 1..3
+  constexpr int STAGE = NF + NB;       // double2 per LDS stage
+  constexpr int RF = (SPB * 36 + 255) / 256;  // register slots per thread for the forward run
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double2* Ls = reinterpret_cast<double2*>(smem);  // [2][STAGE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sl = wave * SPW + lane / M;
+  const int j = lane % M;
+  // scalar copies of the geometry
+  const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
+  const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
+  const int sp0 = lat.split[0], sp1 = lat.split[1], sp2 = lat.split[2], sp3 = lat.split[3];
+  const int64_t gm0 = lat.ghost_off[0][0], gp0 = lat.ghost_off[0][1];
+  const int64_t gm1 = lat.ghost_off[1][0], gp1 = lat.ghost_off[1][1];
+  const int64_t gm2 = lat.ghost_off[2][0], gp2 = lat.ghost_off[2][1];
+  const int64_t gm3 = lat.ghost_off[3][0], gp3 = lat.ghost_off[3][1];
+  const int og0 = lat.origin[0], og1 = lat.origin[1], og2 = lat.origin[2];
+  GramAcc<16> G;
+  if (GRAM) gram_zero(G);
+
+  // ---- tile sequence of this block
+  const int r0 = hw.p0 / SPB, r1 = hw.p1, r2 = hw.p2, r3 = L3, r4 = L0 / hw.p0, r5 = L1 / hw.p1;
+  unsigned start = blockIdx.x, step = gridDim.x, left;
+  if (hw.xcd_split) {
+    const unsigned cnt = ntiles >> 3, cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    step = gridDim.x >> 3;
+    start = cls * cnt + idx;
+    left = idx < cnt ? (cnt - idx + step - 1) / step : 0;
+  } else {
+    left = start < static_cast<unsigned>(ntiles) ? (ntiles - start + step - 1) / step : 0;
+  }
+  Digits dg = digits_of(start, r0, r1, r2, r3, r4, r5);
+  const Digits ds = digits_of(step, r0, r1, r2, r3, r4, r5);
+  // ---- link registers: forward run, the one extra link U_0(x0b - 1), backward links of directions 1..3
+  constexpr int RBM = (SPB * 9 + 255) / 256;
+  dv2 rf[RF], rx, rb1[RBM], rb2[RBM], rb3[RBM];
+  rx = dv2{0.0, 0.0};
+#define BCG_FETCH_LINKS(g)                                                                                        \
+  {                                                                                                               \
+    fetch_fwd<SPB, RF>(U + static_cast<int64_t>((g).site0) * 36, tid, rf);                                        \
+    if (tid < 9) {                                                                                                \
+      const double2* src;                                                                                         \
+      if ((g).x0b > 0) src = U + (static_cast<int64_t>((g).site0) - 1) * 36;                                      \
+      else if (!sp0) src = U + (static_cast<int64_t>((g).site0) + L0 - 1) * 36;                                   \
+      else src = Ughost + (gm0 + ((g).x1 + L1 * ((g).x2 + L2 * (g).x3))) * 9;                                     \
+      rx = *reinterpret_cast<const dv2*>(src + tid);                                                              \
+    }                                                                                                             \
+    fetch_back<SPB, RBM>(1, (g).x1, L1, S1, sp1, gm1, (g).x0b + L0 * ((g).x2 + L2 * (g).x3), (g).site0, U, Ughost, tid, rb1); \
+    fetch_back<SPB, RBM>(2, (g).x2, L2, S2, sp2, gm2, (g).x0b + L0 * ((g).x1 + L1 * (g).x3), (g).site0, U, Ughost, tid, rb2); \
+    fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
+  }
+
+  TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+  if (left > 0) BCG_FETCH_LINKS(g)
+  int stage = 0;
+  for (unsigned it = 0; it < left; ++it) {
+    {  // park the links fetched for this tile in the current LDS stage
+      dv2* Lf = reinterpret_cast<dv2*>(Ls + stage * STAGE);
+      dv2* Lb = Lf + NF;
+#pragma unroll
+      for (int k = 0; k < RF; ++k) {
+        const int e = tid + 256 * k;
+        if (e < SPB * 36) Lf[36 + e] = rf[k];
+      }
+      if (tid < 9) Lf[tid] = rx;  // slot of "site -1", direction 0
+#pragma unroll
+      for (int k = 0; k < RBM; ++k) {
+        const int e = tid + 256 * k;
+        if (e < SPB * 9) {
+          Lb[e] = rb1[k];
+          Lb[SPB * 9 + e] = rb2[k];
+          Lb[2 * SPB * 9 + e] = rb3[k];
+        }
+      }
+    }
+    __syncthreads();
+    const TileGeom cur = g;
+    if (it + 1 < left) {  // prefetch the next tile's links; they land while this tile computes
+      digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
+      g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+      BCG_FETCH_LINKS(g)
+    }
+    const double2* Lf = Ls + stage * STAGE;
+    const double2* Lb = Lf + NF;
+    stage ^= 1;
+    // ---- neighbour tiles: uniform over the block except direction 0
+    const int64_t site0 = cur.site0;
+    const int x0 = cur.x0b + sl;
+    const int64_t me = site0 + sl;
+    const int f0 = cur.x1 + L1 * (cur.x2 + L2 * cur.x3);          // face index of direction 0
+    const int f1 = cur.x0b + L0 * (cur.x2 + L2 * cur.x3);          // directions 1..3: index of the tile's first site
+    const int f2 = cur.x0b + L0 * (cur.x1 + L1 * cur.x3);
+    const int f3 = cur.x0b + L0 * (cur.x1 + L1 * cur.x2);
+    const double2 *nf0, *nb0, *nf1, *nb1, *nf2, *nb2, *nf3, *nb3;
+    if (x0 + 1 < L0) nf0 = in + (me + 1) * 3 * M;
+    else if (!sp0) nf0 = in + (me + 1 - L0) * 3 * M;
+    else nf0 = ghost + (gp0 + f0) * 3 * M;
+    if (x0 > 0) nb0 = in + (me - 1) * 3 * M;
+    else if (!sp0) nb0 = in + (me - 1 + L0) * 3 * M;
+    else nb0 = ghost + (gm0 + f0) * 3 * M;
+#define BCG_NB(MU, XM, LM, SM, SPM, GM, GP, FI, NF_, NB_)                                   \
+  {                                                                                         \
+    if ((XM) + 1 < (LM)) NF_ = in + (me + (SM)) * 3 * M;                                    \
+    else if (!(SPM)) NF_ = in + (me - static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
+    else NF_ = ghost + ((GP) + (FI) + sl) * 3 * M;                                          \
+    if ((XM) > 0) NB_ = in + (me - (SM)) * 3 * M;                                           \
+    else if (!(SPM)) NB_ = in + (me + static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
+    else NB_ = ghost + ((GM) + (FI) + sl) * 3 * M;                                          \
+  }
+    BCG_NB(1, cur.x1, L1, S1, sp1, gm1, gp1, f1, nf1, nb1)
+    BCG_NB(2, cur.x2, L2, S2, sp2, gm2, gp2, f2, nf2, nb2)
+    BCG_NB(3, cur.x3, L3, S3, sp3, gm3, gp3, f3, nf3, nb3)
+#undef BCG_NB
+    // ---- all 24 neighbour loads first, then the arithmetic
+    double2 f[4][3], bk[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
+      f[1][k] = nf1[k * M + j]; bk[1][k] = nb1[k * M + j];
+      f[2][k] = nf2[k * M + j]; bk[2][k] = nb2[k * M + j];
+      f[3][k] = nf3[k * M + j]; bk[3][k] = nb3[k * M + j];
+    }
+    double2 pv[3];
+    const int64_t o0 = me * 3 * M + j;
+    if (MODE == HOP_SHIFTED) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pv[r] = p[o0 + r * M];
+    }
+    double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+    const int par1 = x0 + og0, par2 = par1 + cur.x1 + og1, par3 = par2 + cur.x2 + og2;
+#pragma unroll
+    for (int mu = 0; mu < 4; ++mu) {
+      const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));  // x_0 + ... + x_{mu-1}, global
+      const double eta = (par & 1) ? -1.0 : 1.0;
+      const double2* uf = Lf + (sl + 1) * 36 + mu * 9;
+      const double2* ub = mu == 0 ? Lf + sl * 36 : Lb + ((mu - 1) * SPB + sl) * 9;
+      double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double2 u = uf[k * 3 + r];   // U(r,k)
+          t[r].x = fma(u.x, f[mu][k].x, t[r].x); t[r].x = fma(-u.y, f[mu][k].y, t[r].x);
+          t[r].y = fma(u.x, f[mu][k].y, t[r].y); t[r].y = fma(u.y, f[mu][k].x, t[r].y);
+          const double2 v = ub[r * 3 + k];   // U_b(k,r); subtract conj(v) * psi_b(k)
+          t[r].x = fma(-v.x, bk[mu][k].x, t[r].x); t[r].x = fma(-v.y, bk[mu][k].y, t[r].x);
+          t[r].y = fma(-v.x, bk[mu][k].y, t[r].y); t[r].y = fma(v.y, bk[mu][k].x, t[r].y);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        acc[r].x = fma(eta, t[r].x, acc[r].x);
+        acc[r].y = fma(eta, t[r].y, acc[r].y);
+      }
+    }
+    double2 tv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+      else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+      out[o0 + r * M] = tv[r];
+    }
+    if (GRAM) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
+    }
+  }
+#undef BCG_FETCH_LINKS
   if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
 }
 
@@ -664,18 +998,57 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
   return grid;
 }
 
+template <int M>
+static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
+                       const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
+                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int flags) {
+  constexpr int SPB = 4 * (64 / M);
+  const int ntiles = static_cast<int>(lat.V / SPB);
+  const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
+                   lat.L[2] % p2 == 0 && ntiles % 8 == 0 && max_blocks % 8 == 0 && ntiles / 8 >= max_blocks / 8;
+  HopWalk hw{lat.L[0], lat.L[1], lat.L[2], 0};  // lexicographic = one patch
+  if (ok3) hw = HopWalk{p0, p1, p2, 1};
+  int grid = ntiles < max_blocks ? ntiles : max_blocks;
+  if (hw.xcd_split) grid &= ~7;
+  const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
+  const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
+  const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+  if (gram && M == 16 && mode == HOP_SHIFTED) {
+    hipLaunchKernelGGL((k_hop4<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
+                       partials, ntiles, hw, flags);
+  } else if (mode == HOP_PLAIN) {
+    hipLaunchKernelGGL((k_hop4<M, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
+                       partials, ntiles, hw, flags);
+  } else {
+    hipLaunchKernelGGL((k_hop4<M, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
+                       partials, ntiles, hw, flags);
+  }
+  return grid;
+}
+
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, int c2, int walk) {
+                    double2* partials, bool gram, int max_blocks, int c2, int walk, int flags, int p0, int p1, int p2) {
   const int spb = 4 * (64 / m);
+  // specialised 4-D kernel: tile = spb consecutive x0 sites of one row, 32-bit site arithmetic
+  if (!(flags & 64) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3]) {
+    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
+    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
+    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
+  }
+  if (walk == 3) {
+    const bool ok3 = lat.ndim == 4 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % spb == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
+                     lat.L[2] % p2 == 0 && ((lat.L[0] / p0) * (lat.L[1] / p1) * (lat.L[2] / p2)) % 8 == 0 && max_blocks % 8 == 0;
+    if (!ok3) walk = 2;
+  }
   const bool blockable = lat.ndim == 4 && lat.L[0] % spb == 0 && c2 > 0 && lat.L[2] % c2 == 0;
   if (walk == 2 && !(blockable && lat.L[1] % 8 == 0 && max_blocks % 8 == 0)) walk = blockable ? 1 : 0;
   if (walk == 1 && !blockable) walk = 0;
   const int64_t ntiles = walk > 0 ? lat.V / spb : (lat.V + spb - 1) / spb;
   int grid = grid_tiles(ntiles, 1, max_blocks);
-  if (walk == 2) {
+  if (walk >= 2) {
     grid &= ~7;
-    if (grid < 8) { walk = 1; grid = grid_tiles(ntiles, 1, max_blocks); }
+    if (grid < 8) { walk = blockable ? 1 : 0; grid = grid_tiles(ntiles, 1, max_blocks); }
   }
   const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
@@ -684,14 +1057,14 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
   {                                                                                                                         \
     if (mode == HOP_PLAIN)                                                                                                  \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
-                         p, c0, partials, ntiles, c2, walk);                                                                \
+                         p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);                                                                \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost,    \
-                         out, p, c0, partials, ntiles, c2, walk);                                                           \
+                         out, p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);                                                           \
   }
   if (gram && m == 16 && mode == HOP_SHIFTED) {
     hipLaunchKernelGGL((k_hop_fast<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out,
-                       p, c0, partials, ntiles, c2, walk);
+                       p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);
   } else if (m == 8) BCG_HOP(8) else if (m == 16) BCG_HOP(16) else BCG_HOP(32)
 #undef BCG_HOP
   return grid;

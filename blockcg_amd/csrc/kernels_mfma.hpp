@@ -24,6 +24,6 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, int c2, int walk);
+                    double2* partials, bool gram, int max_blocks, int c2, int walk, int flags, int p0, int p1, int p2);
 
 }  // namespace bcg

@@ -264,3 +264,30 @@ def test_cache_blocked_stencil_walk(bc, orc, c2, monkeypatch):
     out = bc.block_fermion_field(ctx, m)
     D.op(out, bc.block_fermion_field(ctx, m, Bh))
     assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.2, Bh)) < TOL_KERNEL
+
+
+@pytest.mark.parametrize("m,dims", [(16, [32, 4, 2, 6]), (16, [16, 2, 2, 2]), (8, [32, 2, 4, 2]), (32, [8, 4, 4, 2]), (32, [16, 2, 2, 4])])
+@pytest.mark.parametrize("walk,blocks", [("0", "768"), ("3", "8"), ("0", "3")])
+def test_specialised_4d_stencil(bc, orc, m, dims, walk, blocks, monkeypatch):
+    """k_hop4 (tile = consecutive x0 sites, double-buffered link staging) in every walk order, with more
+    tiles than blocks so that the prefetch pipeline wraps, against the oracle's hop and op."""
+    monkeypatch.setenv("BCG_HOP_WALK", walk)
+    monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
+    monkeypatch.setenv("BCG_HOP_PATCH", f"{4 * (64 // m)},2,2")
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 51)
+    Bh = orc.fill_field(m, V, 52)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, 0.3, U=U)
+    x = bc.block_fermion_field(ctx, m, Bh)
+    out = bc.block_fermion_field(ctx, m)
+    D.D(out, x)
+    assert rel_err(out.download(), orc.hop(U, dims, Bh)) < TOL_KERNEL
+    D.op(out, x)
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.3, Bh)) < TOL_KERNEL
+    if m == 16:  # fused Gram variant of the second hop (solver path): two iterations against the oracle
+        X = [bc.block_fermion_field(ctx, m)]
+        info = bc.SBCGrQ(X, x, D, [0.01], 0.0, 0.0, max_iterations=2, trace_limit=2, return_info=True)
+        o = orc.sbcgrq(U, dims, 0.3, Bh, [0.01], 0.0, 0.0, max_iterations=2, trace_limit=2)
+        assert rel_err(info["trace"]["alpha"], o["trace"]["alpha"]) < TOL_COEFF
+        assert rel_err(X[0].download(), o["X"][0]) < 1e-11

@@ -13,12 +13,13 @@ import blockcg_amd as bc  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dims, m = [64, 64, 64, 64], 16
-configs = [(0, 0, 768), (0, 0, 1024), (1, 8, 768), (2, 4, 768), (2, 8, 768), (2, 16, 768), (2, 8, 512), (2, 8, 1024),
-           (2, 8, 1536), (2, 2, 768)]
-for walk, c2, blocks in configs:
+configs = [(3, "16,8,8", 512, 0), (3, "16,8,8", 512, 1), (3, "16,8,4", 512, 0), (3, "16,8,4", 512, 1), (3, "16,4,8", 512, 0), (3, "32,4,4", 512, 0),
+           (3, "32,8,4", 512, 1), (3, "16,16,4", 512, 1), (3, "16,8,8", 512, 9), (3, "16,8,2", 512, 1), (3, "32,4,8", 512, 1)]
+for walk, patch, blocks, flags in configs:
     os.environ["BCG_HOP_WALK"] = str(walk)
-    os.environ["BCG_HOP_C2"] = str(c2)
+    os.environ["BCG_HOP_PATCH"] = patch
     os.environ["BCG_HOP_BLOCKS"] = str(blocks)
+    os.environ["BCG_HOP_FLAGS"] = str(flags)
     ctx = bc.Context(dims)
     D = bc.dirac_op(ctx, 0.1, seed=1)
     x = bc.block_fermion_field(ctx, m).setRandom(seed=2)
@@ -35,7 +36,7 @@ for walk, c2, blocks in configs:
     prof = ctx.profile()
     hop_ms = prof["hop"]["ms"] / prof["hop"]["count"]
     hs = prof.get("hop_shifted", {"ms": 0, "count": 1})
-    print(json.dumps({"walk": walk, "c2": c2, "blocks": blocks, "hop_ms": round(hop_ms, 3),
+    print(json.dumps({"walk": walk, "patch": patch, "blocks": blocks, "flags": flags, "hop_ms": round(hop_ms, 3),
                       "hop_shifted_ms": round(hs["ms"] / hs["count"], 3),
                       "hop_GBps_alg": round(ctx.V * (2 * 48 * m + 576) / hop_ms / 1e6, 1)}), flush=True)
     del x, y, D, ctx
