@@ -35,6 +35,8 @@ SIGNATURES = {
     "bcg_context_set_comm": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(bcg_comm)]),
     "bcg_local_volume": (ctypes.c_int64, [ctypes.c_void_p]),
     "bcg_local_dims": (ctypes.c_int, [ctypes.c_void_p, c_int_p, c_int_p]),
+    "bcg_halo_plan": (ctypes.c_int, [ctypes.c_int, c_int_p, c_int_p, c_int_p, ctypes.c_size_t, c_int_p, c_int_p, c_size_p,
+                                     c_size_p, c_size_p, ctypes.POINTER(ctypes.c_int64)]),
     "bcg_halo_buffers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                         c_size_p]),
     "bcg_synchronize": (ctypes.c_int, [ctypes.c_void_p]),

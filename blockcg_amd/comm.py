@@ -39,6 +39,50 @@ def coords_of(rank, grid):
     return c
 
 
+def halo_plan(dims, grid, coords, site_bytes):
+    """The library's message plan for one halo exchange (bcg_halo_plan; pure host code, no GPU needed).
+    Returns (messages, ghost_sites); a message is (peer_send, peer_recv, send_offset, recv_offset, nbytes)."""
+    lib = _lib.load()
+    nd = len(dims)
+    iv = lambda v: (ctypes.c_int * nd)(*[int(x) for x in v])  # noqa: E731
+    ps, pr = (ctypes.c_int * 8)(), (ctypes.c_int * 8)()
+    so, ro, nb = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)()
+    ghost = ctypes.c_int64(0)
+    n = lib.bcg_halo_plan(nd, iv(dims), iv(grid), iv(coords), site_bytes, ps, pr, so, ro, nb, ctypes.byref(ghost))
+    if n < 0:
+        raise ValueError("invalid decomposition")
+    return [(ps[k], pr[k], so[k], ro[k], nb[k]) for k in range(n)], ghost.value
+
+
+def exchange_messages(send, recv, msgs, group=None, direct=False, sync=None):
+    """Move the faces of one halo exchange.  send/recv: flat uint8 tensors (device memory when `direct`,
+    i.e. backend nccl = RCCL; otherwise staged through host memory for gloo).  Messages to the same peer
+    are matched by posting order (RCCL point-to-point has no tags); gloo also gets the message index as tag."""
+    if direct:
+        ops = []
+        for ps, pr, so, ro, nb in msgs:
+            ops.append(dist.P2POp(dist.isend, send[so:so + nb], ps, group))
+            ops.append(dist.P2POp(dist.irecv, recv[ro:ro + nb], pr, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return
+    if sync is not None:
+        sync()
+    reqs, stage = [], []
+    for k, (ps, pr, so, ro, nb) in enumerate(msgs):
+        s = send[so:so + nb].cpu().contiguous()
+        r = torch.empty(nb, dtype=torch.uint8)
+        stage.append((ro, nb, r, s))
+        reqs.append(dist.isend(s, ps, group=group, tag=k))
+        reqs.append(dist.irecv(r, pr, group=group, tag=k))
+    for w in reqs:
+        w.wait()
+    for ro, nb, r, _ in stage:
+        recv[ro:ro + nb].copy_(r)
+    if sync is not None:
+        sync()
+
+
 class _DevMem:
     """Expose library-owned device memory to torch without copying."""
 
@@ -86,28 +130,9 @@ class TorchDistComm:
             sp, rp, each = self.ctx.halo_buffers()
             send = self._view(sp, each)
             recv = self._view(rp, each)
+            msgs = [(peer_s[k], peer_r[k], off_s[k], off_r[k], nbytes[k]) for k in range(n)]
             with torch.cuda.stream(self.stream):
-                if self.direct:
-                    ops = []
-                    for k in range(n):
-                        ops.append(dist.P2POp(dist.isend, send[off_s[k]:off_s[k] + nbytes[k]], peer_s[k], self.group))
-                        ops.append(dist.P2POp(dist.irecv, recv[off_r[k]:off_r[k] + nbytes[k]], peer_r[k], self.group))
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
-                else:
-                    self.stream.synchronize()
-                    reqs, stage = [], []
-                    for k in range(n):
-                        s = send[off_s[k]:off_s[k] + nbytes[k]].cpu()
-                        r = torch.empty(nbytes[k], dtype=torch.uint8)
-                        stage.append((k, r))
-                        reqs.append(dist.isend(s, peer_s[k], group=self.group, tag=k))
-                        reqs.append(dist.irecv(r, peer_r[k], group=self.group, tag=k))
-                    for w in reqs:
-                        w.wait()
-                    for k, r in stage:
-                        recv[off_r[k]:off_r[k] + nbytes[k]].copy_(r)
-                    self.stream.synchronize()
+                exchange_messages(send, recv, msgs, self.group, self.direct, sync=self.stream.synchronize)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             self.error = e

@@ -181,36 +181,59 @@ inline int64_t rows_of(const bcg_context* c) { return c->lat.V * 3; }
 inline size_t field_bytes(const bcg_context* c, int m) { return static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2); }
 
 // ---- halo exchange -----------------------------------------------------------------------------
-int rank_of(const bcg_context* c, const int* xyz) {
-  // rank = lexicographic index of grid coordinates, direction 0 fastest
+// rank = lexicographic index of grid coordinates, direction 0 fastest
+int rank_of_grid(const int* grid, const int* xyz) {
   int r = 0, st = 1;
   for (int mu = 0; mu < 4; ++mu) {
     r += xyz[mu] * st;
-    st *= c->grid[mu];
+    st *= grid[mu];
   }
   return r;
 }
 
-// Post the face messages for rows of `row_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).
+// The message plan of one halo exchange (pure host arithmetic, shared by bcg_halo_plan and the
+// context).  Ghost/send buffers hold, per split direction in ascending mu, [minus face][plus face]
+// (send buffer: [low face x_mu = 0][high face x_mu = L-1]); a face has V_local / L_mu sites.
+//   message 2k  : low face  -> minus neighbour (becomes its plus ghost); my plus ghost  <- plus neighbour
+//   message 2k+1: high face -> plus neighbour  (becomes its minus ghost); my minus ghost <- minus neighbour
+int halo_plan(int ndim, const int* gdims, const int* grid, const int* coords, size_t site_bytes, int* peer_s, int* peer_r,
+              size_t* off_s, size_t* off_r, size_t* nb, int64_t* ghost_sites) {
+  int g4[4] = {1, 1, 1, 1}, c4[4] = {0, 0, 0, 0}, L[4] = {1, 1, 1, 1};
+  int64_t V = 1;
+  for (int mu = 0; mu < ndim; ++mu) {
+    g4[mu] = grid ? grid[mu] : 1;
+    c4[mu] = coords ? coords[mu] : 0;
+    if (g4[mu] < 1 || gdims[mu] < 1 || gdims[mu] % g4[mu] != 0 || c4[mu] < 0 || c4[mu] >= g4[mu]) return -1;
+    L[mu] = gdims[mu] / g4[mu];
+    V *= L[mu];
+  }
+  int n = 0;
+  int64_t ghost = 0;
+  for (int mu = 0; mu < ndim; ++mu) {
+    if (g4[mu] == 1) continue;
+    int xm[4], xp[4];
+    for (int nu = 0; nu < 4; ++nu) xm[nu] = xp[nu] = c4[nu];
+    xm[mu] = (c4[mu] - 1 + g4[mu]) % g4[mu];
+    xp[mu] = (c4[mu] + 1) % g4[mu];
+    const int rm = rank_of_grid(g4, xm), rp = rank_of_grid(g4, xp);
+    const int64_t face_sites = V / L[mu];
+    const size_t face = static_cast<size_t>(face_sites) * site_bytes;
+    const size_t base = static_cast<size_t>(ghost) * site_bytes;
+    peer_s[n] = rm; peer_r[n] = rp; off_s[n] = base; off_r[n] = base + face; nb[n] = face; ++n;
+    peer_s[n] = rp; peer_r[n] = rm; off_s[n] = base + face; off_r[n] = base; nb[n] = face; ++n;
+    ghost += 2 * face_sites;
+  }
+  if (ghost_sites) *ghost_sites = ghost;
+  return n;
+}
+
+// Post the face messages for `site_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).
 int exchange_faces(bcg_context* c, size_t site_bytes) {
   if (!c->have_comm || !c->comm.halo_exchange) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
   int peer_s[8], peer_r[8];
   size_t off_s[8], off_r[8], nb[8];
-  int n = 0;
-  for (int mu = 0; mu < c->ndim; ++mu) {
-    if (!c->lat.split[mu]) continue;
-    int xm[4], xp[4];
-    for (int nu = 0; nu < 4; ++nu) xm[nu] = xp[nu] = c->coords[nu];
-    xm[mu] = (c->coords[mu] - 1 + c->grid[mu]) % c->grid[mu];
-    xp[mu] = (c->coords[mu] + 1) % c->grid[mu];
-    const int rm = rank_of(c, xm), rp = rank_of(c, xp);
-    const size_t face = static_cast<size_t>(c->lat.face_sites[mu]) * site_bytes;
-    const size_t base = static_cast<size_t>(c->lat.ghost_off[mu][0]) * site_bytes;
-    // low face -> minus neighbour (its plus ghost); my plus ghost <- plus neighbour's low face
-    peer_s[n] = rm; peer_r[n] = rp; off_s[n] = base; off_r[n] = base + face; nb[n] = face; ++n;
-    // high face -> plus neighbour (its minus ghost); my minus ghost <- minus neighbour's high face
-    peer_s[n] = rp; peer_r[n] = rm; off_s[n] = base + face; off_r[n] = base; nb[n] = face; ++n;
-  }
+  const int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
+  if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
   if (c->comm.halo_exchange(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0)
     BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
   return BCG_OK;
@@ -584,6 +607,13 @@ int bcg_local_dims(const bcg_context* c, int* dims4, int* origin4) {
     if (origin4) origin4[mu] = c->lat.origin[mu];
   }
   return BCG_OK;
+}
+
+int bcg_halo_plan(int ndim, const int* global_dims, const int* grid, const int* coords, size_t site_bytes, int* peer_send,
+                  int* peer_recv, size_t* send_offset, size_t* recv_offset, size_t* nbytes, int64_t* ghost_sites) {
+  if (ndim < 1 || ndim > 4 || !global_dims || !peer_send || !peer_recv || !send_offset || !recv_offset || !nbytes) return -1;
+  return halo_plan(ndim, global_dims, grid, coords, site_bytes, peer_send, peer_recv, send_offset, recv_offset, nbytes,
+                   ghost_sites);
 }
 
 int bcg_halo_buffers(bcg_context* c, void** send, void** recv, size_t* bytes_each) {

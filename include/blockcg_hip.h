@@ -80,8 +80,17 @@ const char* bcg_last_error(const bcg_context* ctx); /* ctx may be NULL: last cre
 int bcg_context_set_comm(bcg_context* ctx, const bcg_comm* comm);
 int64_t bcg_local_volume(const bcg_context* ctx);
 int bcg_local_dims(const bcg_context* ctx, int* dims4_out, int* origin4_out);
-/* Device halo buffers (valid after the first field of width m was created); for wrapping as
- * communicator-visible tensors. */
+/* Pure host helper, needs no device: the message plan one halo exchange of this rank would pass to
+ * bcg_comm.halo_exchange for `site_bytes` bytes per site (48*m for a field, 144 for links).  Arrays need
+ * capacity 8 (2 messages per split direction).  Buffers hold, per split direction in ascending mu,
+ * [minus face][plus face], each V_local/L_mu sites in lexicographic order of the other coordinates.
+ * Message 2k sends the low face (x_mu = 0) to the minus neighbour and receives the plus ghost from the
+ * plus neighbour; message 2k+1 sends the high face to the plus neighbour and receives the minus ghost.
+ * Returns the number of messages, or a negative value for an invalid decomposition. */
+int bcg_halo_plan(int ndim, const int* global_dims, const int* grid, const int* coords, size_t site_bytes, int* peer_send,
+                  int* peer_recv, size_t* send_offset, size_t* recv_offset, size_t* nbytes, int64_t* ghost_sites);
+/* Device halo buffers (valid after the first exchange was sized); for wrapping as communicator-visible
+ * tensors. */
 int bcg_halo_buffers(bcg_context* ctx, void** send, void** recv, size_t* bytes_each);
 int bcg_synchronize(bcg_context* ctx);
 /* Per-kernel timing with HIP events on the context's stream (off by default).  Names and
