@@ -94,6 +94,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = int(os.environ.get("BCG_DEVICE", local_rank))  # BCG_DEVICE: rehearse several ranks on one GPU (with gloo)
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     dist = None
@@ -102,19 +103,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from blockcg_amd.comm import TorchDistComm, coords_of, grid_for
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=os.environ.get("BCG_BACKEND", "nccl"),
-                                device_id=torch.device("cuda", local_rank) if os.environ.get("BCG_BACKEND", "nccl") == "nccl" else None)
+        torch.cuda.set_device(device)
+        backend = os.environ.get("BCG_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=backend, device_id=torch.device("cuda", device) if backend == "nccl" else None)
         grid = grid_for(world, ndim)
         coords = coords_of(rank, grid)
-        comm = TorchDistComm(local_rank)
+        comm = TorchDistComm(device)
         gdims = [l * g for l, g in zip(args.local_dims, grid)]
-        ctx = bc.Context(gdims, device=local_rank, grid=grid, coords=coords, stream=comm.stream_ptr)
+        ctx = bc.Context(gdims, device=device, grid=grid, coords=coords, stream=comm.stream_ptr)
         comm.attach(ctx)
     else:
         grid = [1] * ndim
         gdims = list(args.local_dims)
-        ctx = bc.Context(gdims, device=local_rank)
+        ctx = bc.Context(gdims, device=device)
     if args.generic:
         ctx.force_generic(True)
 

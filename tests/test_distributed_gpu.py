@@ -38,3 +38,49 @@ def test_domain_decomposed_solve(dims, grid, m, generic):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU_OK" in out.stdout
+
+
+def test_rccl_on_library_memory_views():
+    """Backend nccl (= RCCL) on the tensor views bench.py builds over library-owned device memory: an
+    all-reduce and a batched self send/recv in a world of one (the only RCCL world a one-GPU box allows)."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["BCG_ROOT"])
+from blockcg_amd.comm import _DevMem, exchange_messages
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+base = torch.arange(4096, dtype=torch.float64, device="cuda")
+view = torch.as_tensor(_DevMem(base.data_ptr(), base.numel() * 8, "<f8", 8), device="cuda")
+assert view.data_ptr() == base.data_ptr()
+dist.all_reduce(view)
+torch.cuda.synchronize()
+assert torch.equal(view, torch.arange(4096, dtype=torch.float64, device="cuda"))
+send = torch.as_tensor(_DevMem(base.data_ptr(), 4096 * 8), device="cuda")
+dst = torch.zeros(4096 * 8, dtype=torch.uint8, device="cuda")
+recv = torch.as_tensor(_DevMem(dst.data_ptr(), 4096 * 8), device="cuda")
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    exchange_messages(send, recv, [(0, 0, 0, 1024, 2048), (0, 0, 2048, 8192, 4096)], None, direct=True)
+s.synchronize()
+assert torch.equal(dst[1024:3072], send[0:2048]) and torch.equal(dst[8192:12288], send[2048:6144])
+dist.destroy_process_group()
+print("RCCL_VIEW_OK")
+'''
+    env = dict(os.environ, BCG_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29651", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_VIEW_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path end to end (gloo, both ranks on GPU 0, small local volume)."""
+    env = dict(os.environ, BCG_BACKEND="gloo", BCG_DEVICE="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29652", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--local-dims", "16", "16", "16", "16"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["global_dims"] == [16, 16, 16, 32]
