@@ -1,0 +1,29 @@
+// blockcg/block_solvers.hpp -- drop-in for SBCGrQ of the reference's inc/block_solvers.hpp:91-185.
+//
+// Same signature and return value (number of operator applications).  The whole iteration runs inside
+// libblockcg_hip.so (host control flow + m x m algebra in C++, every loop over sites a HIP kernel).
+// The reference's asserts (:97-101) become exceptions; they are not compiled out.
+#ifndef BLOCKCG_BLOCK_SOLVERS_HPP
+#define BLOCKCG_BLOCK_SOLVERS_HPP
+#include <algorithm>
+
+#include "dirac_op.hpp"
+#include "fields.hpp"
+
+// SBCGrQ inversion of (D + sigma_j) X^{sigma_j} = B
+template <int N_rhs>
+int SBCGrQ(std::vector<block_fermion_field<N_rhs>>& X, const block_fermion_field<N_rhs>& B, const dirac_op& D,
+           std::vector<double>& sigma, double eps = 1.e-15, double eps_shifts = 1.e-15, int max_iterations = 1e6) {
+  if (sigma.size() != X.size()) throw std::invalid_argument("number of shifts does not match number of solution vectors");
+  std::vector<bcg_field*> Xh(X.size());
+  for (size_t s = 0; s < X.size(); ++s) Xh[s] = X[s].handle();
+  B.flush();
+  int iterations = 0;
+  blockcg::check(bcg_sbcgrq_solve(D.lat().ctx(), D.handle(), D.mass, Xh.data(), B.handle(), static_cast<int>(X.size()),
+                                  sigma.data(), eps, eps_shifts, max_iterations, /*consume_B=*/0, &iterations, nullptr, nullptr),
+                 D.lat().ctx(), "SBCGrQ");
+  for (auto& x : X) x.device_written();
+  return iterations;
+}
+
+#endif

@@ -1,0 +1,80 @@
+"""The C++ drop-in headers (blockcg_amd/include/blockcg/*.hpp) with the reference's names.
+
+CPU: they compile with a plain host compiler against the C ABI, and their std::rand()-based setRandom
+draws exactly the reference's values (so srand(k) reproduces the reference's lattices and sources).
+GPU: the reference's own SBCGrQ unit test and benchmark driver, rewritten against the headers, pass."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+INC = os.path.join(ROOT, "blockcg_amd", "include")
+LIBDIR = os.path.join(ROOT, "blockcg_amd", "_build")
+OUT = os.path.join(ROOT, "examples", "_build")
+
+
+def _compile(src, exe, link=True):
+    os.makedirs(OUT, exist_ok=True)
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-I", INC, src, "-o", os.path.join(OUT, exe)]
+    if link:
+        cmd += ["-L", LIBDIR, "-lblockcg_hip", f"-Wl,-rpath,{LIBDIR}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return os.path.join(OUT, exe)
+
+
+@pytest.fixture(scope="module")
+def built():
+    import blockcg_amd
+    if not os.path.exists(blockcg_amd.LIB_PATH):
+        blockcg_amd.build()
+    return {"test": _compile(os.path.join(ROOT, "examples", "test_solvers.cpp"), "test_solvers"),
+            "bench": _compile(os.path.join(ROOT, "examples", "benchmark.cpp"), "benchmark")}
+
+
+def test_headers_compile_with_host_compiler(built):
+    assert os.path.exists(built["test"]) and os.path.exists(built["bench"])
+
+
+def test_setrandom_reproduces_reference_draws():
+    import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "random_probe.cpp"), "random_probe", link=False)
+    V = 16
+    raw = np.frombuffer(subprocess.run([exe, "5", str(V)], capture_output=True).stdout, dtype=np.float64)
+    U = raw[:V * 18].view(np.complex128).reshape(V, 1, 3, 3)
+    B = raw[V * 18:].view(np.complex128).reshape(V, 4, 3)
+    R = oracle.Reference()
+    Uref = R.make_dirac_1d(V, 0.1, 5)   # srand(5); dirac_op D(V, mass)
+    Bref = R.field_random(4, V)         # rand() state continues into B.setRandom()
+    assert np.array_equal(U, Uref)
+    assert np.array_equal(B, Bref)
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_against_headers(built):
+    r = subprocess.run([built["test"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SBCGrQ 1-D V=128 N_rhs=3" in r.stdout and "FAILED" not in r.stdout
+    # 42-44 iterations at the reference's test configuration
+    it = int(re.search(r"N_rhs=3: iterations (\d+)", r.stdout).group(1))
+    assert 41 <= it <= 44
+
+
+@pytest.mark.gpu
+def test_benchmark_driver_matches_reference_run(built):
+    """`./benchmark 100 0.1 1e-10` of the unmodified reference (built here from /root/reference) printed
+    SBCGrQ_iterations 360 and a shift-0 residual of 6.416677e-11; same default rand() seed, same lattice."""
+    r = subprocess.run([built["bench"], "100", "0.1", "1e-10"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert int(re.search(r"SBCGrQ_iterations:\s+(\d+)", r.stdout).group(1)) == 360
+    res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
+    assert len(res) == 9 and abs(res[0] - 6.416677e-11) / 6.416677e-11 < 1e-2
+    ref = [6.416677e-11, 6.416697e-11, 6.416718e-11, 6.416649e-11, 6.414947e-11, 6.399223e-11, 6.245456e-11, 7.270243e-12,
+           2.186446e-15]
+    assert np.allclose(res[:8], ref[:8], rtol=2e-2)
