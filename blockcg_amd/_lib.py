@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libblockcg_hip.so")
+LIB_PATH = os.environ.get("BCG_LIB") or os.path.join(_HERE, "_build", "libblockcg_hip.so")  # BCG_LIB: A/B builds
 
 c_dbl_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)

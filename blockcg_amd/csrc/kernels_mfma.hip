@@ -730,13 +730,18 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
   }
 }
 
-template <int M, int MODE, bool GRAM>
+// Measured on one device (tools/ab_bench.sh): carrying the -x3 neighbours / U_3(x-3) across steps pays for the
+// fused-Gram variant (15.6 -> 13.8 ms at 64^4) but not for the plain hop (11.7 -> 13.0 ms), and asking for a minimum
+// of 2 waves per SIMD in __launch_bounds__ costs 1.5 ms on both, so: CARRY = GRAM, plain __launch_bounds__(256).
+template <int M, int MODE, bool GRAM, bool NT>
 __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                               const double2* __restrict__ ghost, double2* __restrict__ out,
                                               const double2* __restrict__ p, double c0,
                                               double2* __restrict__ partials, int ntiles, HopWalk hw, int flags) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  constexpr bool CARRY = GRAM;
+  constexpr int STAGES = CARRY ? 3 : 2;
   (void)flags;  // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
@@ -746,10 +751,16 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   constexpr int STAGE = NF + NB;       // double2 per LDS stage
   constexpr int RF = (SPB * 36 + 255) / 256;  // register slots per thread for the forward run
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double2* Ls = reinterpret_cast<double2*>(smem);  // [2][STAGE]
+  double2* Ls = reinterpret_cast<double2*>(smem);  // [3][STAGE] link images
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sl = wave * SPW + lane / M;
   const int j = lane % M;
+  // x3 carry: under the patch walk a block visits (tile, x3), (tile, x3+1), ... so the -x3 neighbour of step n is
+  // the +x3 neighbour this lane loaded at step n-2 (kept in registers), and U_3(x-3) is the forward link
+  // of step n-1, still in the other link stage.  Both would otherwise be re-fetched past L2.
+  dv2 h1[3], h2[3];  // the lane's +x3 neighbour values of the previous two steps (registers)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h1[k] = h2[k] = dv2{0.0, 0.0};
   // scalar copies of the geometry
   const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
   const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
@@ -779,7 +790,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   constexpr int RBM = (SPB * 9 + 255) / 256;
   dv2 rf[RF], rx, rb1[RBM], rb2[RBM], rb3[RBM];
   rx = dv2{0.0, 0.0};
-#define BCG_FETCH_LINKS(g)                                                                                        \
+#define BCG_FETCH_LINKS(g, SKIP3)                                                                                      \
   {                                                                                                               \
     fetch_fwd<SPB, RF>(U + static_cast<int64_t>((g).site0) * 36, tid, rf);                                        \
     if (tid < 9) {                                                                                                \
@@ -791,12 +802,16 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     }                                                                                                             \
     fetch_back<SPB, RBM>(1, (g).x1, L1, S1, sp1, gm1, (g).x0b + L0 * ((g).x2 + L2 * (g).x3), (g).site0, U, Ughost, tid, rb1); \
     fetch_back<SPB, RBM>(2, (g).x2, L2, S2, sp2, gm2, (g).x0b + L0 * ((g).x1 + L1 * (g).x3), (g).site0, U, Ughost, tid, rb2); \
-    fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
+    if (!(SKIP3))                                                                                                 \
+      fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
   }
 
   TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
-  if (left > 0) BCG_FETCH_LINKS(g)
+  if (left > 0) BCG_FETCH_LINKS(g, false)
   int stage = 0;
+  int site_m1 = -1;          // site0 of the previous tile of this block
+  int fsite_m1 = -1, fsite_m2 = -1;  // first site of the +x3 neighbour tile loaded 1 and 2 steps ago (-1: ghost)
+  bool carry_u3 = false;     // this tile's U_3(x-3) is the previous tile's forward link
   for (unsigned it = 0; it < left; ++it) {
     {  // park the links fetched for this tile in the current LDS stage
       dv2* Lf = reinterpret_cast<dv2*>(Ls + stage * STAGE);
@@ -813,20 +828,26 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
         if (e < SPB * 9) {
           Lb[e] = rb1[k];
           Lb[SPB * 9 + e] = rb2[k];
-          Lb[2 * SPB * 9 + e] = rb3[k];
+          if (!carry_u3) Lb[2 * SPB * 9 + e] = rb3[k];
         }
       }
     }
     __syncthreads();
     const TileGeom cur = g;
+    const bool cur_carry_u3 = carry_u3;
     if (it + 1 < left) {  // prefetch the next tile's links; they land while this tile computes
       digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
       g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
-      BCG_FETCH_LINKS(g)
+      carry_u3 = CARRY && g.x3 > 0 && g.site0 - S3 == cur.site0;
+      BCG_FETCH_LINKS(g, carry_u3)
     }
+    // With the carry three stages, not two: the previous tile's image is READ here (U_3 carry) while a faster wave of this
+    // block may already be parking the next tile; with three stages that park goes to the third image, and an
+    // image is only re-written after the barrier that follows every wave's last read of it.
     const double2* Lf = Ls + stage * STAGE;
     const double2* Lb = Lf + NF;
-    stage ^= 1;
+    const double2* Lf_prev = Ls + (stage == 0 ? STAGES - 1 : stage - 1) * STAGE;  // the previous tile's links
+    stage = stage == STAGES - 1 ? 0 : stage + 1;
     // ---- neighbour tiles: uniform over the block except direction 0
     const int64_t site0 = cur.site0;
     const int x0 = cur.x0b + sl;
@@ -856,19 +877,38 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     BCG_NB(3, cur.x3, L3, S3, sp3, gm3, gp3, f3, nf3, nb3)
 #undef BCG_NB
     // ---- all 24 neighbour loads first, then the arithmetic
+    const bool carry_b3 = CARRY && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
+    const int fsite_now = (cur.x3 + 1 < L3) ? cur.site0 + S3 : (sp3 ? -1 : cur.site0 - (L3 - 1) * S3);
     double2 f[4][3], bk[4][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
       f[1][k] = nf1[k * M + j]; bk[1][k] = nb1[k * M + j];
       f[2][k] = nf2[k * M + j]; bk[2][k] = nb2[k * M + j];
-      f[3][k] = nf3[k * M + j]; bk[3][k] = nb3[k * M + j];
+      f[3][k] = nf3[k * M + j];
     }
+    if (carry_b3) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bk[3][k] = make_double2(h2[k].x, h2[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bk[3][k] = nb3[k * M + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      h2[k] = h1[k];
+      h1[k].x = f[3][k].x;
+      h1[k].y = f[3][k].y;
+    }
+    fsite_m2 = fsite_m1;
+    fsite_m1 = fsite_now;
+    site_m1 = cur.site0;
+    (void)site_m1;
     double2 pv[3];
     const int64_t o0 = me * 3 * M + j;
     if (MODE == HOP_SHIFTED) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) pv[r] = p[o0 + r * M];
+      for (int r = 0; r < 3; ++r) pv[r] = NT ? ld_nt(p + o0 + r * M) : p[o0 + r * M];
     }
     double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
     const int par1 = x0 + og0, par2 = par1 + cur.x1 + og1, par3 = par2 + cur.x2 + og2;
@@ -877,7 +917,8 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
       const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));  // x_0 + ... + x_{mu-1}, global
       const double eta = (par & 1) ? -1.0 : 1.0;
       const double2* uf = Lf + (sl + 1) * 36 + mu * 9;
-      const double2* ub = mu == 0 ? Lf + sl * 36 : Lb + ((mu - 1) * SPB + sl) * 9;
+      const double2* ub = mu == 0 ? Lf + sl * 36
+                                  : ((mu == 3 && cur_carry_u3) ? Lf_prev + (sl + 1) * 36 + 27 : Lb + ((mu - 1) * SPB + sl) * 9);
       double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -902,7 +943,8 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     for (int r = 0; r < 3; ++r) {
       if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
       else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-      out[o0 + r * M] = tv[r];
+      if (NT) st_nt(out + o0 + r * M, tv[r]);  // streamed once: keep it from displacing the patch slices in L2
+      else out[o0 + r * M] = tv[r];
     }
     if (GRAM) {
 #pragma unroll
@@ -1010,19 +1052,24 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   if (ok3) hw = HopWalk{p0, p1, p2, 1};
   int grid = ntiles < max_blocks ? ntiles : max_blocks;
   if (hw.xcd_split) grid &= ~7;
-  const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
+  const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+#define BCG_LAUNCH4(MM, MD, GR, NTV)                                                                                     \
+  do {                                                                                                                   \
+    allow_lds(k_hop4<MM, MD, GR, NTV>, lds);                                                                             \
+    hipLaunchKernelGGL((k_hop4<MM, MD, GR, NTV>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0, \
+                       partials, ntiles, hw, flags);                                                                     \
+  } while (0)
+  const bool nt = (flags & 1) != 0;
   if (gram && M == 16 && mode == HOP_SHIFTED) {
-    hipLaunchKernelGGL((k_hop4<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
-                       partials, ntiles, hw, flags);
+    if (nt) BCG_LAUNCH4(16, HOP_SHIFTED, true, true); else BCG_LAUNCH4(16, HOP_SHIFTED, true, false);
   } else if (mode == HOP_PLAIN) {
-    hipLaunchKernelGGL((k_hop4<M, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
-                       partials, ntiles, hw, flags);
+    if (nt) BCG_LAUNCH4(M, HOP_PLAIN, false, true); else BCG_LAUNCH4(M, HOP_PLAIN, false, false);
   } else {
-    hipLaunchKernelGGL((k_hop4<M, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0,
-                       partials, ntiles, hw, flags);
+    if (nt) BCG_LAUNCH4(M, HOP_SHIFTED, false, true); else BCG_LAUNCH4(M, HOP_SHIFTED, false, false);
   }
+#undef BCG_LAUNCH4
   return grid;
 }
 

@@ -154,7 +154,7 @@ def test_config1_32c4_m8_solves_to_tolerance(bc):
     D = bc.dirac_op(ctx, mass, seed=11)
     B = bc.block_fermion_field(ctx, m).setRandom(seed=12)
     X = [bc.block_fermion_field(ctx, m)]
-    it = bc.SBCGrQ(X, B, D, [0.0], eps)
+    it = bc.SBCGrQ(X, B, D, [0.0], eps, max_iterations=2000)
     assert 0 < it < 2000
     AX = bc.block_fermion_field(ctx, m)
     D.op(AX, X[0])
@@ -184,8 +184,8 @@ def test_config2_64c4_m16_4shifts_solves_to_tolerance(bc):
     D = bc.dirac_op(ctx, mass, seed=21)
     B = bc.block_fermion_field(ctx, m).setRandom(seed=22)
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
-    it = bc.SBCGrQ(X, B, D, shifts, eps, eps)
-    assert 0 < it < 1000
+    it = bc.SBCGrQ(X, B, D, shifts, eps, eps, max_iterations=400)  # bounded: a wrong stencil must fail, not spin
+    assert 0 < it < 400
     b2 = np.real(np.diag(B.hermitian_dot(B)))
     AX = bc.block_fermion_field(ctx, m)
     for s, sig in enumerate(shifts):
@@ -291,3 +291,26 @@ def test_specialised_4d_stencil(bc, orc, m, dims, walk, blocks, monkeypatch):
         o = orc.sbcgrq(U, dims, 0.3, Bh, [0.01], 0.0, 0.0, max_iterations=2, trace_limit=2)
         assert rel_err(info["trace"]["alpha"], o["trace"]["alpha"]) < TOL_COEFF
         assert rel_err(X[0].download(), o["X"][0]) < 1e-11
+
+
+@pytest.mark.parametrize("blocks", ["32", "64"])
+def test_stencil_x3_carry_path(bc, orc, blocks, monkeypatch):
+    """Per-XCD patch walk with as many blocks per class as tiles per patch slice: every block then visits
+    (tile, x3), (tile, x3+1), ... and takes its -x3 neighbours from the LDS ring and U_3(x-3) from the previous
+    link image (kernels_mfma.hip, k_hop4) instead of global memory."""
+    monkeypatch.setenv("BCG_HOP_WALK", "3")
+    monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    dims, m = [16, 4, 4, 16], 16
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 61)
+    Bh = orc.fill_field(m, V, 62)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, 0.2, U=U)
+    x = bc.block_fermion_field(ctx, m, Bh)
+    out = bc.block_fermion_field(ctx, m)
+    for _ in range(3):
+        D.D(out, x)
+        assert rel_err(out.download(), orc.hop(U, dims, Bh)) < TOL_KERNEL
+    D.op(out, x)
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.2, Bh)) < TOL_KERNEL

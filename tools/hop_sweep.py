@@ -13,8 +13,7 @@ import blockcg_amd as bc  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dims, m = [64, 64, 64, 64], 16
-configs = [(3, "16,8,8", 512, 0), (3, "16,8,8", 512, 1), (3, "16,8,4", 512, 0), (3, "16,8,4", 512, 1), (3, "16,4,8", 512, 0), (3, "32,4,4", 512, 0),
-           (3, "32,8,4", 512, 1), (3, "16,16,4", 512, 1), (3, "16,8,8", 512, 9), (3, "16,8,2", 512, 1), (3, "32,4,8", 512, 1)]
+configs = [(3, "16,8,8", 512, 1), (3, "16,8,8", 768, 1), (3, "16,8,8", 768, 0), (3, "16,8,4", 768, 1), (3, "32,8,4", 768, 1), (3, "16,8,8", 1024, 1)]
 for walk, patch, blocks, flags in configs:
     os.environ["BCG_HOP_WALK"] = str(walk)
     os.environ["BCG_HOP_PATCH"] = patch
