@@ -5,4 +5,5 @@ classes mirror the reference's interface names (block_fermion_field, dirac_op, S
 drop-in headers live in blockcg_amd/include/blockcg/.
 """
 from ._lib import build, load, LIB_PATH  # noqa: F401
-from .api import (BlockCGError, Context, block_fermion_field, dirac_op, SBCGrQ, SBCGrQState, SUPPORTED_WIDTHS)  # noqa: F401
+from .api import (BlockCGError, Context, block_fermion_field, dirac_op, SBCGrQ, SBCGrQState, SUPPORTED_WIDTHS, true_residuals,
+                  CG, SCG, BCG, BCGrQ)  # noqa: F401

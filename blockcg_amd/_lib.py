@@ -77,6 +77,17 @@ SIGNATURES = {
     "bcg_sbcgrq_iterate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_int_p, c_dbl_p,
                                           ctypes.POINTER(bcg_sbcgrq_trace)]),
     "bcg_sbcgrq_end": (ctypes.c_int, [ctypes.c_void_p]),
+    "bcg_true_residuals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p),
+                                          ctypes.c_void_p, ctypes.c_int, c_dbl_p, c_dbl_p]),
+    "bcg_cg_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_double, ctypes.c_int, c_int_p]),
+    "bcg_scg_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.c_void_p, ctypes.c_int, c_dbl_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                     c_int_p]),
+    "bcg_bcg_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_double, ctypes.c_int, c_int_p]),
+    "bcg_bcgrq_solve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_double, ctypes.c_int, c_int_p]),
     "bcg_sbcgrq_bytes_per_iteration": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
 }
 

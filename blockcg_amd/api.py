@@ -313,3 +313,48 @@ class SBCGrQState:
             self.end()
         except Exception:
             pass
+
+
+def true_residuals(X, B, D, sigma):
+    """Reference acceptance measure (test/solvers.cpp:104-116) on the device; returns [n_shifts, N_rhs]."""
+    ctx = B.ctx
+    S = len(X)
+    sig = np.ascontiguousarray(sigma, dtype=np.float64)
+    Xh = (ctypes.c_void_p * S)(*[x.h for x in X])
+    res = np.empty((S, B.N_rhs), dtype=np.float64)
+    ctx.check(ctx.lib.bcg_true_residuals(ctx.h, D.h, D.mass, Xh, B.h, S, _dp(sig), _dp(res)))
+    return res
+
+
+def CG(x, b, D, eps=1.e-15, max_iterations=1000000):
+    """src/standard_solvers.cpp:3-32"""
+    it = ctypes.c_int(0)
+    b.ctx.check(b.ctx.lib.bcg_cg_solve(b.ctx.h, D.h, D.mass, x.h, b.h, eps, int(max_iterations), ctypes.byref(it)))
+    return it.value
+
+
+def SCG(x, b, D, sigma, eps=1.e-15, eps_shifts=1.e-15, max_iterations=1000000):
+    """src/standard_solvers.cpp:34-95"""
+    S = len(x)
+    if len(sigma) != S:
+        raise ValueError("number of shifts does not match number of solution vectors")
+    sig = np.ascontiguousarray(sigma, dtype=np.float64)
+    xh = (ctypes.c_void_p * S)(*[v.h for v in x])
+    it = ctypes.c_int(0)
+    b.ctx.check(b.ctx.lib.bcg_scg_solve(b.ctx.h, D.h, D.mass, xh, b.h, S, _dp(sig), eps, eps_shifts, int(max_iterations),
+                                        ctypes.byref(it)))
+    return it.value
+
+
+def BCG(X, B, D, eps=1.e-15, max_iterations=1000000):
+    """inc/block_solvers.hpp:10-45"""
+    it = ctypes.c_int(0)
+    B.ctx.check(B.ctx.lib.bcg_bcg_solve(B.ctx.h, D.h, D.mass, X.h, B.h, eps, int(max_iterations), ctypes.byref(it)))
+    return it.value
+
+
+def BCGrQ(X, B, D, eps=1.e-15, max_iterations=1000000):
+    """inc/block_solvers.hpp:50-86"""
+    it = ctypes.c_int(0)
+    B.ctx.check(B.ctx.lib.bcg_bcgrq_solve(B.ctx.h, D.h, D.mass, X.h, B.h, eps, int(max_iterations), ctypes.byref(it)))
+    return it.value

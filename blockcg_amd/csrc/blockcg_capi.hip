@@ -858,6 +858,196 @@ int bcg_dirac_apply(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* 
   return apply_shifted(c, g, mass, 0.0, out, in);
 }
 
+// ---- the callers either side of the hot path, on the same kernels ------------
+}  // extern "C"
+
+namespace {
+
+// Re(a^dagger b) for N_rhs = 1 fields: real_dot (inc/fields.hpp:93-99)
+int real_dot(bcg_context* c, const bcg_field* a, const bcg_field* b, double& out) {
+  CMat G;
+  BCG_TRY(gram(c, a, b, G, false));
+  out = G(0, 0).real();
+  return BCG_OK;
+}
+
+struct FieldPool {  // work fields of one solver call, released together
+  bcg_context* c;
+  std::vector<bcg_field*> f;
+  explicit FieldPool(bcg_context* ctx) : c(ctx) {}
+  ~FieldPool() {
+    for (bcg_field* p : f) bcg_field_destroy(p);
+  }
+  int make(int m, bcg_field** out, const bcg_field* init = nullptr) {
+    bcg_field* p = nullptr;
+    BCG_TRY(bcg_field_create(c, m, &p));
+    f.push_back(p);
+    if (init) BCG_TRY(bcg_field_copy(p, init));
+    *out = p;
+    return BCG_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+// True relative residuals exactly as the reference's tests and benchmark measure them
+// (test/solvers.cpp:104-116, benchmark.cpp:93-103): AX = op(X_s) + sigma_s X_s - B ;
+// res[s][i] = sqrt( (AX^dagger AX)_ii / (B^dagger B)_ii ).
+int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, const bcg_field* B,
+                       int n_shifts, const double* sigma, double* res_out) {
+  if (!c || !g || !X || !B || !sigma || !res_out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
+  const int m = B->m;
+  FieldPool pool(c);
+  bcg_field* AX;
+  BCG_TRY(pool.make(m, &AX));
+  CMat b2, r2;
+  BCG_TRY(gram(c, B, B, b2));
+  for (int s = 0; s < n_shifts; ++s) {
+    if (!same_shape(X[s], B)) return BCG_ERR_INVALID;
+    BCG_TRY(apply_shifted(c, g, mass, sigma[s], AX, X[s]));  // op + add(X_s, sigma_s) in one pass
+    BCG_TRY(axpby(c, AX, 1.0, B, -1.0, "axpby"));
+    BCG_TRY(gram(c, AX, AX, r2));
+    for (int i = 0; i < m; ++i) res_out[s * m + i] = std::sqrt(r2(i, i).real() / b2(i, i).real());
+  }
+  return BCG_OK;
+}
+
+// CG (src/standard_solvers.cpp:3-32): single right-hand side, scalar coefficients.
+int bcg_cg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* x, const bcg_field* b, double eps,
+                 int max_iterations, int* iterations_out) {
+  if (!c || !g || !same_shape(x, b) || x == b || g->ctx != c || b->ctx != c) return BCG_ERR_INVALID;
+  if (b->m != 1) BCG_FAIL(c, BCG_ERR_INVALID, "CG takes fermion_field arguments (N_rhs = 1)");
+  FieldPool pool(c);
+  bcg_field *t, *p, *r;
+  BCG_TRY(bcg_field_set_zero(x));  // :5
+  BCG_TRY(pool.make(1, &t));
+  BCG_TRY(pool.make(1, &p, b));    // :7
+  BCG_TRY(pool.make(1, &r, b));    // :8
+  double rr, pt;
+  BCG_TRY(real_dot(c, r, r, rr));  // :9
+  int iter = 0;
+  const double stop = eps * std::sqrt(rr);  // :11
+  while (std::sqrt(rr) > stop && iter < max_iterations) {  // :13
+    BCG_TRY(apply_shifted(c, g, mass, 0.0, t, p));          // :15
+    ++iter;
+    BCG_TRY(real_dot(c, p, t, pt));
+    const double alpha = rr / pt;                           // :18
+    BCG_TRY(axpby(c, r, 1.0, t, -alpha, "axpby"));          // :20
+    const double rr_old = rr;
+    BCG_TRY(real_dot(c, r, r, rr));                         // :23
+    const double beta = rr / rr_old;                        // :24
+    BCG_TRY(axpby(c, x, 1.0, p, alpha, "axpby"));           // :26
+    BCG_TRY(axpby(c, p, beta, r, 1.0, "axpby"));            // :28
+  }
+  BCG_TRY(stream_sync(c));
+  if (iterations_out) *iterations_out = iter;
+  return BCG_OK;
+}
+
+// SCG (src/standard_solvers.cpp:34-95): multi-shift CG, scalar zeta/theta recurrences.
+int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* x, const bcg_field* b, int n_shifts,
+                  const double* sigma, double eps, double eps_shifts, int max_iterations, int* iterations_out) {
+  if (!c || !g || !x || !b || !sigma || n_shifts < 1 || g->ctx != c || b->ctx != c) return BCG_ERR_INVALID;
+  if (b->m != 1) BCG_FAIL(c, BCG_ERR_INVALID, "SCG takes fermion_field arguments (N_rhs = 1)");
+  for (int s = 0; s < n_shifts; ++s)
+    if (!same_shape(x[s], b) || x[s] == b) return BCG_ERR_INVALID;
+  if (sigma[0] < 0.0) BCG_FAIL(c, BCG_ERR_INVALID, "SCG: shifts must be zero or positive");              // :40
+  if (!std::is_sorted(sigma, sigma + n_shifts)) BCG_FAIL(c, BCG_ERR_INVALID, "SCG: shifts must be ascending");  // :41-42
+  int active = n_shifts;                       // :45
+  double alpha = 1.0, beta = 0.0;              // :46-47
+  std::vector<double> zeta(n_shifts, 1.0), theta(n_shifts, 1.0);  // :48-49
+  FieldPool pool(c);
+  std::vector<bcg_field*> p(n_shifts);
+  for (int s = 0; s < n_shifts; ++s) {
+    BCG_TRY(bcg_field_set_zero(x[s]));         // :50-52
+    BCG_TRY(pool.make(1, &p[s], b));           // :53
+  }
+  bcg_field *t, *r;
+  BCG_TRY(pool.make(1, &t));
+  BCG_TRY(pool.make(1, &r, b));                // :54
+  double rr, pt;
+  BCG_TRY(real_dot(c, r, r, rr));              // :55
+  int iter = 0;
+  const double stop = eps * std::sqrt(rr);     // :57
+  while (std::sqrt(rr) > stop && iter < max_iterations) {  // :58
+    BCG_TRY(apply_shifted(c, g, mass, sigma[0], t, p[0]));  // :60-61
+    ++iter;
+    const double alpha_old = alpha;
+    BCG_TRY(real_dot(c, p[0], t, pt));
+    alpha = rr / pt;                                        // :65
+    BCG_TRY(axpby(c, r, 1.0, t, -alpha, "axpby"));          // :67
+    const double rr_old = rr;
+    BCG_TRY(real_dot(c, r, r, rr));                         // :69
+    const double beta_old = beta;
+    beta = rr / rr_old;                                     // :71
+    BCG_TRY(axpby(c, x[0], 1.0, p[0], alpha, "axpby"));     // :73
+    BCG_TRY(axpby(c, p[0], beta, r, 1.0, "axpby"));         // :75
+    for (int s = active - 1; s > 0; --s) {                  // :76
+      double inv_theta = 1.0 + (sigma[s] - sigma[0]) * alpha;              // :78
+      inv_theta += beta_old * (alpha / alpha_old) * (1.0 - theta[s]);      // :79
+      theta[s] = 1.0 / inv_theta;                                          // :80
+      zeta[s] *= theta[s];                                                 // :81
+      const double alpha_s = alpha * theta[s];                             // :82
+      const double beta_s = beta * theta[s] * theta[s];                    // :83
+      BCG_TRY(axpby(c, x[s], 1.0, p[s], alpha_s, "axpby"));                // :85
+      BCG_TRY(axpby(c, p[s], beta_s, r, zeta[s], "axpby"));                // :87
+    }
+    if (std::sqrt(rr) * zeta[active - 1] < eps_shifts) --active;           // :90-92
+  }
+  BCG_TRY(stream_sync(c));
+  if (iterations_out) *iterations_out = iter;
+  return BCG_OK;
+}
+
+// BCG (inc/block_solvers.hpp:10-45): block CG without the QR stabilisation.
+int bcg_bcg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
+                  int max_iterations, int* iterations_out) {
+  if (!c || !g || !same_shape(X, B) || X == B || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
+  const int m = B->m;
+  FieldPool pool(c);
+  bcg_field *T, *P, *R;
+  BCG_TRY(bcg_field_set_zero(X));   // :14
+  BCG_TRY(pool.make(m, &T));
+  BCG_TRY(pool.make(m, &P, B));     // :16
+  BCG_TRY(pool.make(m, &R, B));
+  CMat r2, r2_old, pt;
+  BCG_TRY(gram(c, R, R, r2));       // :17
+  std::vector<double> norm0(m);
+  for (int i = 0; i < m; ++i) norm0[i] = std::sqrt(r2(i, i).real());  // :19-20
+  double residual = 1.0;
+  int iter = 0;
+  while (residual > eps && iter < max_iterations) {          // :25
+    BCG_TRY(apply_shifted(c, g, mass, 0.0, T, P));            // :27
+    ++iter;
+    BCG_TRY(gram(c, P, T, pt));
+    if (!pt.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "BCG: P^dagger A P is not finite");
+    const CMat alpha = bcg::inverse_full_pivot(pt) * r2;      // :31  (P.T)^-1 (R.R)
+    BCG_TRY(rmul(c, R, T, -alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));  // :33
+    r2_old = r2;
+    BCG_TRY(gram(c, R, R, r2));                               // :35
+    const CMat beta = bcg::inverse_full_pivot(r2_old) * r2;   // :36
+    BCG_TRY(rmul(c, X, P, alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));   // :38
+    BCG_TRY(rmul(c, P, R, beta, 1.0, bcg::RMUL_XPAY, "block_xpay"));   // :40
+    residual = 0.0;                                           // :41-42
+    for (int i = 0; i < m; ++i) residual = std::max(residual, std::sqrt(r2(i, i).real()) / norm0[i]);
+  }
+  BCG_TRY(stream_sync(c));
+  if (iterations_out) *iterations_out = iter;
+  return BCG_OK;
+}
+
+// BCGrQ (inc/block_solvers.hpp:50-86) is SBCGrQ with the single shift sigma = 0: same statements in the same
+// order (X += P alpha delta_old, Q -= T alpha, thinQR, P = P rho^dagger + Q, delta = rho delta).
+int bcg_bcgrq_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
+                    int max_iterations, int* iterations_out) {
+  const double zero = 0.0;
+  bcg_field* Xs[1] = {X};
+  return bcg_sbcgrq_solve(c, g, mass, Xs, const_cast<bcg_field*>(B), 1, &zero, eps, 0.0, max_iterations, 0, iterations_out,
+                          nullptr, nullptr);
+}
+
 double bcg_sbcgrq_bytes_per_iteration(const bcg_context* c, int m, int n_shifts) {
   if (!c) return 0.0;
   const double s = 48.0 * m, gl = 144.0 * c->ndim;

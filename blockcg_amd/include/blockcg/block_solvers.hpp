@@ -26,4 +26,28 @@ int SBCGrQ(std::vector<block_fermion_field<N_rhs>>& X, const block_fermion_field
   return iterations;
 }
 
+// BCG inversion of D X = B (inc/block_solvers.hpp:10-12); returns the number of operator applications
+template <int N_rhs>
+int BCG(block_fermion_field<N_rhs>& X, const block_fermion_field<N_rhs>& B, const dirac_op& D, double eps = 1.e-15,
+        int max_iterations = 1e6) {
+  B.flush();
+  int iterations = 0;
+  blockcg::check(bcg_bcg_solve(D.lat().ctx(), D.handle(), D.mass, X.handle(), B.handle(), eps, max_iterations, &iterations),
+                 D.lat().ctx(), "BCG");
+  X.device_written();
+  return iterations;
+}
+
+// BCGrQ inversion of D X = B (inc/block_solvers.hpp:50-52)
+template <int N_rhs>
+int BCGrQ(block_fermion_field<N_rhs>& X, const block_fermion_field<N_rhs>& B, const dirac_op& D, double eps = 1.e-15,
+          int max_iterations = 1e6) {
+  B.flush();
+  int iterations = 0;
+  blockcg::check(bcg_bcgrq_solve(D.lat().ctx(), D.handle(), D.mass, X.handle(), B.handle(), eps, max_iterations, &iterations),
+                 D.lat().ctx(), "BCGrQ");
+  X.device_written();
+  return iterations;
+}
+
 #endif

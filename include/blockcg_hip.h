@@ -171,6 +171,22 @@ int bcg_sbcgrq_iterate(bcg_sbcgrq_state* state, int max_new_iterations, int* ite
                        bcg_sbcgrq_trace* trace);
 int bcg_sbcgrq_end(bcg_sbcgrq_state* state);
 
+/* ---- the callers either side of the hot path, on the same kernels ---------- */
+/* True relative residuals as the reference's tests and benchmark measure them (test/solvers.cpp:104-116,
+ * benchmark.cpp:93-103): res_out[s*m + i] = |(A + sigma_s) X_s - B|_i / |B|_i. */
+int bcg_true_residuals(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* const* X, const bcg_field* B,
+                       int n_shifts, const double* sigma, double* res_out);
+/* CG  src/standard_solvers.cpp:3-32   and   SCG  src/standard_solvers.cpp:34-95   (fields of width 1) */
+int bcg_cg_solve(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* x, const bcg_field* b, double eps,
+                 int max_iterations, int* iterations_out);
+int bcg_scg_solve(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* const* x, const bcg_field* b, int n_shifts,
+                  const double* sigma, double eps, double eps_shifts, int max_iterations, int* iterations_out);
+/* BCG  inc/block_solvers.hpp:10-45   and   BCGrQ  inc/block_solvers.hpp:50-86 */
+int bcg_bcg_solve(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
+                  int max_iterations, int* iterations_out);
+int bcg_bcgrq_solve(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
+                    int max_iterations, int* iterations_out);
+
 /* Algorithmic HBM bytes of one SBCGrQ iteration on this rank's sub-lattice:
  *   V_local * [ (14 + 4*(S-1)) * 48*m + 2 * 144*ndim ] */
 double bcg_sbcgrq_bytes_per_iteration(const bcg_context* ctx, int m, int n_shifts);

@@ -202,6 +202,34 @@ class Oracle:
         self._chk(self.lib.orc_true_residuals(m, len(dims), _dims(dims), _dp(U), mass, _dp(B), S, _dp(sig), _dp(X), _dp(res)))
         return res
 
+    # --- the other four solvers ---
+    def cg(self, U, dims, mass, b, eps=1e-15, max_iterations=1000000):
+        b = _f(b); U = np.ascontiguousarray(U, dtype=np.complex128)
+        x = np.empty_like(b); it = ctypes.c_int(0)
+        self.lib.orc_cg.argtypes = [ctypes.c_int, _c_int_p, _c_dbl_p, ctypes.c_double, _c_dbl_p, ctypes.c_double, ctypes.c_int,
+                                    _c_dbl_p, _c_int_p]
+        self.lib.orc_cg(len(dims), _dims(dims), _dp(U), mass, _dp(b), eps, max_iterations, _dp(x), ctypes.byref(it))
+        return x, it.value
+
+    def scg(self, U, dims, mass, b, sigma, eps=1e-15, eps_shifts=1e-15, max_iterations=1000000):
+        b = _f(b); U = np.ascontiguousarray(U, dtype=np.complex128); S = len(sigma)
+        sig = np.ascontiguousarray(sigma, dtype=np.float64)
+        x = np.empty((S,) + b.shape, dtype=np.complex128); it = ctypes.c_int(0)
+        self.lib.orc_scg.argtypes = [ctypes.c_int, _c_int_p, _c_dbl_p, ctypes.c_double, _c_dbl_p, ctypes.c_int, _c_dbl_p,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_dbl_p, _c_int_p]
+        self.lib.orc_scg(len(dims), _dims(dims), _dp(U), mass, _dp(b), S, _dp(sig), eps, eps_shifts, max_iterations, _dp(x),
+                         ctypes.byref(it))
+        return x, it.value
+
+    def bcg(self, U, dims, mass, B, eps=1e-15, max_iterations=1000000, with_qr=False):
+        B = _f(B); U = np.ascontiguousarray(U, dtype=np.complex128)
+        X = np.empty_like(B); it = ctypes.c_int(0)
+        self.lib.orc_bcg.argtypes = [ctypes.c_int, ctypes.c_int, _c_int_p, _c_dbl_p, ctypes.c_double, _c_dbl_p, ctypes.c_double,
+                                     ctypes.c_int, ctypes.c_int, _c_dbl_p, _c_int_p]
+        self._chk(self.lib.orc_bcg(B.shape[1], len(dims), _dims(dims), _dp(U), mass, _dp(B), eps, max_iterations,
+                                   1 if with_qr else 0, _dp(X), ctypes.byref(it)))
+        return X, it.value
+
     def bench_sbcgrq(self, m, dims, mass, sigma, iterations, seed=1):
         """Fixed-work single-thread CPU run on synthetic inputs; returns (seconds_for_iterations, seconds_setup)."""
         sig = np.ascontiguousarray(sigma, dtype=np.float64)
@@ -353,3 +381,27 @@ class Reference:
         res = np.empty((S, m), dtype=np.float64)
         self._chk(self.lib.ref_true_residuals(self._h, m, _dp(B), S, _dp(sig), _dp(X), _dp(res)))
         return res
+
+    def bcg(self, B, eps=1e-15, max_iterations=1000000, with_qr=False):
+        B = _f(B); X = np.empty_like(B); it = ctypes.c_int(0)
+        self.lib.ref_bcg.argtypes = [ctypes.c_void_p, ctypes.c_int, _c_dbl_p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                     _c_dbl_p, _c_int_p]
+        self._chk(self.lib.ref_bcg(self._h, B.shape[1], _dp(B), eps, max_iterations, 1 if with_qr else 0, _dp(X),
+                                   ctypes.byref(it)))
+        return X, it.value
+
+    def cg(self, b, eps=1e-15, max_iterations=1000000):
+        assert not self.four_d
+        b = _f(b); x = np.empty_like(b); it = ctypes.c_int(0)
+        self.lib.ref_cg.argtypes = [ctypes.c_void_p, _c_dbl_p, ctypes.c_double, ctypes.c_int, _c_dbl_p, _c_int_p]
+        self.lib.ref_cg(self._h, _dp(b), eps, max_iterations, _dp(x), ctypes.byref(it))
+        return x, it.value
+
+    def scg(self, b, sigma, eps=1e-15, eps_shifts=1e-15, max_iterations=1000000):
+        assert not self.four_d
+        b = _f(b); S = len(sigma); sig = np.ascontiguousarray(sigma, dtype=np.float64)
+        x = np.empty((S,) + b.shape, dtype=np.complex128); it = ctypes.c_int(0)
+        self.lib.ref_scg.argtypes = [ctypes.c_void_p, _c_dbl_p, ctypes.c_int, _c_dbl_p, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, _c_dbl_p, _c_int_p]
+        self.lib.ref_scg(self._h, _dp(b), S, _dp(sig), eps, eps_shifts, max_iterations, _dp(x), ctypes.byref(it))
+        return x, it.value

@@ -225,6 +225,42 @@ int orc_sbcgrq(int m, int ndim, const int* dims, const double* U, double mass, c
   return 0;
 }
 
+int orc_cg(int ndim, const int* dims, const double* U, double mass, const double* b, double eps, int max_iterations,
+           double* x_out, int* iters_out) {
+  Gauge g = load_gauge(ndim, dims, U);
+  Field<1> fb = load_field<1>(g.lat.V, b);
+  Field<1> x(g.lat.V);
+  const int it = CG(x, fb, g, mass, eps, max_iterations);
+  store_field(x, x_out);
+  if (iters_out) *iters_out = it;
+  return 0;
+}
+
+int orc_scg(int ndim, const int* dims, const double* U, double mass, const double* b, int nshift, const double* sigma,
+            double eps, double eps_shifts, int max_iterations, double* x_out, int* iters_out) {
+  Gauge g = load_gauge(ndim, dims, U);
+  const int64_t V = g.lat.V;
+  Field<1> fb = load_field<1>(V, b);
+  std::vector<Field<1>> x(nshift, Field<1>(V));
+  const int it = SCG(x, fb, g, mass, std::vector<double>(sigma, sigma + nshift), eps, eps_shifts, max_iterations);
+  for (int s = 0; s < nshift; ++s) store_field(x[s], x_out + static_cast<size_t>(s) * V * NC * 2);
+  if (iters_out) *iters_out = it;
+  return 0;
+}
+
+int orc_bcg(int m, int ndim, const int* dims, const double* U, double mass, const double* B, double eps, int max_iterations,
+            int with_qr, double* X_out, int* iters_out) {
+  Gauge g = load_gauge(ndim, dims, U);
+  ORC_DISPATCH(m, {
+    Field<M> fB = load_field<M>(g.lat.V, B);
+    Field<M> X(g.lat.V);
+    const int it = with_qr ? BCGrQ<M>(X, fB, g, mass, eps, max_iterations) : BCG<M>(X, fB, g, mass, eps, max_iterations);
+    store_field(X, X_out);
+    if (iters_out) *iters_out = it;
+  });
+  return 0;
+}
+
 // res_out[nshift][m]
 int orc_true_residuals(int m, int ndim, const int* dims, const double* U, double mass, const double* B, int nshift,
                        const double* sigma, const double* X, double* res_out) {

@@ -86,6 +86,9 @@ class dirac_op {
 #endif
 
 #include "block_solvers.hpp"
+#ifndef REF_SUBSTITUTE_OP
+#include "standard_solvers.hpp"  // CG, SCG: compiled from src/standard_solvers.cpp where it lies (oracle/Makefile)
+#endif
 
 namespace {
 using cd = std::complex<double>;
@@ -284,6 +287,43 @@ int ref_sbcgrq(void* h, int m, const double* B, int nshift, const double* sigma,
   });
   return 0;
 }
+
+// The unmodified BCG / BCGrQ (inc/block_solvers.hpp:10-45, 50-86).
+int ref_bcg(void* h, int m, const double* B, double eps, int max_iterations, int with_qr, double* X_out, int* iters_out) {
+  const dirac_op& D = *static_cast<dirac_op*>(h);
+  REF_DISPATCH(m, {
+    block_fermion_field<N> fB = load_field<N>(D.V, B);
+    block_fermion_field<N> X(D.V);
+    const int it = with_qr ? BCGrQ<N>(X, fB, D, eps, max_iterations) : BCG<N>(X, fB, D, eps, max_iterations);
+    if (iters_out) *iters_out = it;
+    store_field(X, X_out);
+  });
+  return 0;
+}
+
+#ifndef REF_SUBSTITUTE_OP
+// The unmodified CG / SCG (src/standard_solvers.cpp:3-32, 34-95).
+int ref_cg(void* h, const double* b, double eps, int max_iterations, double* x_out, int* iters_out) {
+  const dirac_op& D = *static_cast<dirac_op*>(h);
+  fermion_field fb = load_field<1>(D.V, b);
+  fermion_field x(D.V);
+  const int it = CG(x, fb, D, eps, max_iterations);
+  if (iters_out) *iters_out = it;
+  store_field(x, x_out);
+  return 0;
+}
+int ref_scg(void* h, const double* b, int nshift, const double* sigma, double eps, double eps_shifts, int max_iterations,
+            double* x_out, int* iters_out) {
+  const dirac_op& D = *static_cast<dirac_op*>(h);
+  fermion_field fb = load_field<1>(D.V, b);
+  std::vector<double> sig(sigma, sigma + nshift);
+  std::vector<fermion_field> x(nshift, fb);
+  const int it = SCG(x, fb, D, sig, eps, eps_shifts, max_iterations);
+  if (iters_out) *iters_out = it;
+  for (int s = 0; s < nshift; ++s) store_field(x[s], x_out + static_cast<size_t>(s) * D.V * N_f * 2);
+  return 0;
+}
+#endif
 
 // True residuals exactly as test/solvers.cpp:104-116 computes them. res_out[nshift][m].
 int ref_true_residuals(void* h, int m, const double* B, int nshift, const double* sigma, const double* X, double* res_out) {

@@ -18,6 +18,7 @@ Files written (numpy .npz, complex128 in the reference's host layout, see oracle
   ref4d_4x4x4x6_m4.npz ref4d_4x4x2x2_m16.npz ref4d_6x4x4x2_m8.npz
                        reference SBCGrQ + reference field arithmetic over the substitute n-D operator
                        (full data).
+  ref1d_v128_other_solvers.npz  CG, SCG (N_rhs = 1), BCG, BCGrQ (N_rhs = 3) at the reference's test configuration.
   ref4d_8x8x8x8_m4.npz inputs from the oracle's counter-based generator (seeds stored), summary of
                        the reference solve only (iterations, residuals, column norms of X).
 """
@@ -106,6 +107,23 @@ def gen_nd(name, dims, m, mass, shifts, eps, eps_shifts, seed, early, full=True)
     print(name, "iterations", int(d["iterations"]), "max residual", d["residuals"].max())
 
 
+def gen_other_solvers(name):
+    """CG, SCG, BCG, BCGrQ of the unmodified reference at its own test configuration (test/solvers.cpp:8-91)."""
+    V, mass, eps = 128, 0.5, 1e-10
+    shifts = [0.0, 0.01, 0.10, 0.20, 0.9]
+    R = oracle.Reference(four_d=False)
+    U = R.make_dirac_1d(V, mass, 1)
+    b = R.field_random(1, V)
+    B = R.field_random(3, V)
+    d = dict(dims=np.array([V]), mass=mass, eps=eps, shifts=np.array(shifts), U=U, b=b, B=B)
+    d["x_cg"], it = R.cg(b, eps); d["it_cg"] = np.int64(it)
+    d["x_scg"], it = R.scg(b, shifts, eps); d["it_scg"] = np.int64(it)
+    d["X_bcg"], it = R.bcg(B, eps, with_qr=False); d["it_bcg"] = np.int64(it)
+    d["X_bcgrq"], it = R.bcg(B, eps, with_qr=True); d["it_bcgrq"] = np.int64(it)
+    np.savez(os.path.join(OUT, name), **d)
+    print(name, "iterations CG/SCG/BCG/BCGrQ", int(d["it_cg"]), int(d["it_scg"]), int(d["it_bcg"]), int(d["it_bcgrq"]))
+
+
 def main():
     if not oracle.ref_available():
         sys.exit("oracle/_ref is missing: run `make -C oracle ref` where /root/reference exists")
@@ -120,6 +138,7 @@ def main():
     gen_nd("ref4d_4x4x2x2_m16.npz", [4, 4, 2, 2], 16, 0.2, s4, 1e-10, 1e-12, 12, early=2)
     gen_nd("ref4d_6x4x4x2_m8.npz", [6, 4, 4, 2], 8, 0.1, [0.0], 1e-10, 1e-12, 13, early=2)
     gen_nd("ref4d_8x8x8x8_m4.npz", [8, 8, 8, 8], 4, 0.05, s4, 1e-10, 1e-10, 14, early=0, full=False)
+    gen_other_solvers("ref1d_v128_other_solvers.npz")
 
 
 if __name__ == "__main__":

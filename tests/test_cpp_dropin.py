@@ -77,6 +77,11 @@ def test_benchmark_driver_matches_reference_run(built):
     assert r.returncode == 0, r.stdout + r.stderr
     it = int(re.search(r"SBCGrQ_iterations:\s+(\d+)", r.stdout).group(1))
     assert it in (348, 360, 372)
+    # SCG column of the same run of the reference: SCG_iterations 2142, residuals 9.834652e-11 ...
+    it_scg = int(re.search(r"SCG_iterations:\s+(\d+)", r.stdout).group(1))
+    assert abs(it_scg - 2142) <= 12  # 12 columns, +-1 iteration each at the threshold
+    res_scg = [float(x) for x in re.search(r"SCG residuals:\s+(.*)", r.stdout).group(1).split()]
+    assert len(res_scg) == 9 and max(res_scg) < 2e-10
     res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
     assert len(res) == 9 and res[0] < 2e-10
     ref = [6.416677e-11, 6.416697e-11, 6.416718e-11, 6.416649e-11, 6.414947e-11, 6.399223e-11, 6.245456e-11, 7.270243e-12,

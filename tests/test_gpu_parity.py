@@ -13,7 +13,7 @@ from conftest import TOL_COEFF, TOL_KERNEL, TOL_SOLUTION, golden_files, rel_err
 
 pytestmark = pytest.mark.gpu
 
-FULL = [f for f in golden_files() if "8x8x8x8" not in f]
+FULL = [f for f in golden_files() if "8x8x8x8" not in f and "other_solvers" not in f]
 WITH_PRIMS = [f for f in FULL if "v1000" not in f]
 
 
@@ -314,3 +314,51 @@ def test_stencil_x3_carry_path(bc, orc, blocks, monkeypatch):
         assert rel_err(out.download(), orc.hop(U, dims, Bh)) < TOL_KERNEL
     D.op(out, x)
     assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.2, Bh)) < TOL_KERNEL
+
+
+def test_other_solvers_match_reference_fixture(bc, orc):
+    """CG, SCG, BCG, BCGrQ and the on-device true-residual check, against values the
+    unmodified reference computed at its own test configuration (test/solvers.cpp:19-91)."""
+    g = np.load(golden_files("ref1d_v128_other_solvers.npz")[0])
+    dims, mass, eps, shifts = _dims(g), float(g["mass"]), float(g["eps"]), list(g["shifts"])
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, U=g["U"])
+    b = bc.block_fermion_field(ctx, 1, g["b"])
+    B = bc.block_fermion_field(ctx, 3, g["B"])
+    x = bc.block_fermion_field(ctx, 1)
+    it = bc.CG(x, b, D, eps)
+    assert abs(it - int(g["it_cg"])) <= 1 and rel_err(x.download(), g["x_cg"]) < TOL_SOLUTION
+    assert bc.true_residuals([x], b, D, [0.0]).max() < 2 * eps
+    xs = [bc.block_fermion_field(ctx, 1) for _ in shifts]
+    it = bc.SCG(xs, b, D, shifts, eps)
+    assert abs(it - int(g["it_scg"])) <= 1
+    assert rel_err(np.stack([v.download() for v in xs]), g["x_scg"]) < TOL_SOLUTION
+    res = bc.true_residuals(xs, b, D, shifts)
+    assert res.max() < 2 * eps  # REQUIRE(residual < 2 * stopping_criterion), test/solvers.cpp:50
+    assert rel_err(res, orc.true_residuals(g["U"], dims, mass, g["b"], shifts, np.stack([v.download() for v in xs]))) < 1e-3
+    X = bc.block_fermion_field(ctx, 3)
+    it = bc.BCG(X, B, D, eps)
+    assert abs(it - int(g["it_bcg"])) <= 1 and rel_err(X.download(), g["X_bcg"]) < TOL_SOLUTION
+    assert bc.true_residuals([X], B, D, [0.0]).max() < 2 * eps
+    it = bc.BCGrQ(X, B, D, eps)
+    assert abs(it - int(g["it_bcgrq"])) <= 1 and rel_err(X.download(), g["X_bcgrq"]) < TOL_SOLUTION
+    assert bc.true_residuals([X], B, D, [0.0]).max() < 2 * eps
+
+
+def test_other_solvers_on_4d_lattice_mfma_width(bc, orc):
+    """BCG / BCGrQ at block width 16 on a 4-D lattice against the oracle (seeded inputs)."""
+    dims, m, mass, eps = [16, 4, 4, 4], 16, 0.4, 1e-10
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 71)
+    Bh = orc.fill_field(m, V, 72)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, U=U)
+    B = bc.block_fermion_field(ctx, m, Bh)
+    X = bc.block_fermion_field(ctx, m)
+    for with_qr, fn in ((False, bc.BCG), (True, bc.BCGrQ)):
+        it = fn(X, B, D, eps)
+        Xo, ito = orc.bcg(U, dims, mass, Bh, eps, with_qr=with_qr)
+        assert abs(it - ito) <= 1
+        assert bc.true_residuals([X], B, D, [0.0]).max() < 2 * eps
+        if it == ito:
+            assert rel_err(X.download(), Xo) < TOL_SOLUTION

@@ -11,7 +11,7 @@ import pytest
 
 from conftest import TOL_KERNEL, TOL_SOLUTION, golden_files, rel_err
 
-FULL = [f for f in golden_files() if "8x8x8x8" not in f]
+FULL = [f for f in golden_files() if "8x8x8x8" not in f and "other_solvers" not in f]
 WITH_PRIMS = [f for f in FULL if "v1000" not in f]
 
 
@@ -111,3 +111,17 @@ def test_generator_is_split_independent(orc):
     assert np.array_equal(whole[25:], part)
     assert np.abs(whole.real).max() <= 1 and np.abs(whole.imag).max() <= 1
     assert abs(whole.real.mean()) < 0.2
+
+
+def test_other_solvers_match_reference(orc):
+    """CG, SCG, BCG, BCGrQ restatements against the unmodified reference."""
+    g = np.load(golden_files("ref1d_v128_other_solvers.npz")[0])
+    dims, mass, eps, shifts = _dims(g), float(g["mass"]), float(g["eps"]), list(g["shifts"])
+    x, it = orc.cg(g["U"], dims, mass, g["b"], eps)
+    assert it == int(g["it_cg"]) and rel_err(x, g["x_cg"]) < TOL_SOLUTION
+    x, it = orc.scg(g["U"], dims, mass, g["b"], shifts, eps)
+    assert it == int(g["it_scg"]) and rel_err(x, g["x_scg"]) < TOL_SOLUTION
+    X, it = orc.bcg(g["U"], dims, mass, g["B"], eps, with_qr=False)
+    assert it == int(g["it_bcg"]) and rel_err(X, g["X_bcg"]) < TOL_SOLUTION
+    X, it = orc.bcg(g["U"], dims, mass, g["B"], eps, with_qr=True)
+    assert it == int(g["it_bcgrq"]) and rel_err(X, g["X_bcgrq"]) < TOL_SOLUTION
