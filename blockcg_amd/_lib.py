@@ -107,9 +107,13 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(blockcg_amd has no CPU fallback)")
+        # a fresh checkout: compile once with hipcc (it cross-compiles gfx950 without a GPU); there is no CPU fallback
+        try:
+            build()
+        except Exception as e:
+            raise ImportError(
+                f"{LIB_PATH} is missing and `make -C blockcg_amd/csrc` failed ({e}); "
+                "blockcg_amd has no CPU fallback") from e
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync

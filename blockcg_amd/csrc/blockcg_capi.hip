@@ -269,18 +269,6 @@ int halo_gauge(bcg_context* c, bcg_gauge* g) {
 // ---- building blocks ---------------------------------------------------------------------------
 bool same_shape(const bcg_field* a, const bcg_field* b) { return a && b && a->ctx == b->ctx && a->m == b->m; }
 
-// x2 chunk for the stencil's cache-blocked walk: three x3-slices of a chunk (plus the streamed output
-// and links) should stay inside the 256 MiB Infinity Cache, so one slice of the chunk is kept <= 24 MiB.
-int hop_c2_for(const bcg_context* c, int m) {
-  if (c->hop_c2 >= 0) return c->hop_c2;
-  if (c->ndim != 4) return 0;
-  const double plane = static_cast<double>(c->lat.L[0]) * c->lat.L[1] * 48.0 * m;
-  int best = 0;
-  for (int d = 1; d <= c->lat.L[2]; ++d)
-    if (c->lat.L[2] % d == 0 && plane * d <= 24.0 * 1024 * 1024) best = d;
-  return best == c->lat.L[2] ? 0 : best;  // whole extent fits: plain lexicographic order is the same walk
-}
-
 inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }
 inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
 constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
@@ -298,7 +286,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     if (gram) BCG_TRY(ensure_scratch(c));
     ProfScope ps(c, gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted"));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                        p ? p->d : nullptr, c0, c->partials, gram, c->hop_blocks, hop_c2_for(c, m), c->hop_walk, c->hop_flags, c->hop_patch[0], c->hop_patch[1], c->hop_patch[2]);
+                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune);
     if (gram) *gram_blocks = nb;
   } else {
     ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
@@ -540,12 +528,11 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
     }
   }
   c->ghost_sites = ghost;
-  c->hop_c2 = -1;
-  if (const char* e = std::getenv("BCG_HOP_C2")) c->hop_c2 = std::atoi(e);
-  if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_walk = std::atoi(e);
-  if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_blocks = std::atoi(e);
-  if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_flags = std::atoi(e);
-  if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_patch[0], &c->hop_patch[1], &c->hop_patch[2]);
+  // tuning overrides for experiments (tools/hop_sweep.py); defaults in kernels_mfma.hpp
+  if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_tune.patch_walk = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_tune.blocks = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
+  if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {

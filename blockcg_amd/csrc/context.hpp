@@ -8,6 +8,7 @@
 
 #include "../../include/blockcg_hip.h"
 #include "kernels.hpp"
+#include "kernels_mfma.hpp"
 #include "small_matrix.hpp"
 
 struct bcg_field {
@@ -47,11 +48,7 @@ struct bcg_context {
   bcg_comm comm{};
   bool have_comm = false;
   bool force_generic = false;
-  int hop_c2 = -1;      // x2 chunk of the stencil's cache-blocked walk (-1 = auto, 0 = off)
-  int hop_walk = 3;     // 0 lexicographic, 3 per-XCD patches swept along x3 (kernels_mfma.hip); 1, 2: older variants of the general kernel
-  int hop_patch[3] = {16, 8, 8};  // walk 3: (x0,x1,x2) extents of the per-XCD patch swept along x3
-  int hop_flags = 1;    // k_hop4: bit 0 = non-temporal store of out and load of p (streamed once); k_hop_fast: tuning bits
-  int hop_blocks = 512; // persistent grid of the stencil kernel: 2 blocks per CU at its register budget
+  bcg::HopTuning hop_tune;  // specialised stencil: tile walk, patch shape, grid, streaming hints
 
   // scratch
   std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)

@@ -418,12 +418,11 @@ __global__ void __launch_bounds__(256) k_gram_mfma(int64_t rows, const double2* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stencil (K1) fast path.  Block = 256 threads = 4 waves; wave = 64/M sites x M right-hand sides,
-// lane = (site, j).  The 2*ndim links of the block's sites are staged once per tile in LDS by one
-// thread per link (144 contiguous bytes) and then read as LDS broadcasts, instead of every lane
-// fetching every link from global memory.  Blocks walk the lattice in tiles of SPB consecutive x0
-// sites; with c2 > 0 the walk is blocked in x2 (chunks of c2 planes, x3 inside) so that the three
-// x3-slices a chunk needs stay resident in the 256 MiB Infinity Cache.
+// Stencil (K1), general form: any number of dimensions and any extents (the specialised 4-D kernel below
+// takes over when L0 is a multiple of the tile).  Block = 256 threads = 4 waves; wave = 64/M sites x M
+// right-hand sides, lane = (site, j).  The 2*ndim links of the block's sites are staged once per tile in
+// LDS by one thread per link (144 contiguous bytes) and read as LDS broadcasts, instead of every lane
+// fetching every link from global memory.  Blocks walk the lattice in lexicographic tiles of SPB sites.
 // MODE HOP_SHIFTED: out = c0*p - D in; with GRAM (m = 16) also accumulates p^dagger out.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void coords_of(const LatticeDev& lat, int64_t site, int x[4]) {
@@ -448,7 +447,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
                                                   const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                                   const double2* __restrict__ ghost, double2* __restrict__ out,
                                                   const double2* __restrict__ p, double c0,
-                                                  double2* __restrict__ partials, int64_t ntiles, int c2, int walk, int flags, int p0, int p1, int p2) {
+                                                  double2* __restrict__ partials, int64_t ntiles) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
@@ -460,62 +459,11 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
   const int j = lane % M;
   GramAcc<16> G;
   if (GRAM) gram_zero(G);
-  // Tile walk (performance only; every tile is visited exactly once in all three):
-  //  walk 0: block b takes tiles b, b+grid, ...  in lexicographic order.
-  //  walk 1: same, but lexicographic order is blocked in x2 (chunks of c2 planes, x3 inside a chunk).
-  //  walk 2: XCD-aware.  Blocks b and b+8 share an XCD and its 4 MiB L2 (round-robin dispatch), so the
-  //          8 block classes b%8 each own a strip of L1/8 x1-rows; all classes sweep the same x2 chunk
-  //          and x3 slice together.  x0/x1/x2 neighbours are then re-used out of the XCD's own L2 and
-  //          the +-x3 slices of the chunk out of the Infinity Cache.
-  const int tiles_x0 = lat.L[0] / SPB;  // walks 1, 2: host guarantees divisibility
-  int64_t first = blockIdx.x, step = gridDim.x, count = ntiles;
-  int xcd = 0, w1 = 0;
-  //  walk 3: XCD-aware patches.  Each block class b%8 sweeps x3 over a compact patch of p0 x p1 x p2 sites in
-  //          (x0,x1,x2), then takes the next patch; three x3-slices of a patch fit the XCD's L2, so all
-  //          eight neighbour directions are re-used from L2 and only the patch surface is re-fetched.
-  if (walk == 2 || walk == 3) {
-    xcd = blockIdx.x & 7;
-    first = blockIdx.x >> 3;
-    step = gridDim.x >> 3;
-    count = ntiles >> 3;
-    w1 = lat.L[1] >> 3;
-  }
-  const int pt0 = p0 / SPB;                 // tiles along x0 in a patch
-  const int tp = pt0 * p1 * p2;             // tiles per patch slice
-  const int np0 = walk == 3 ? lat.L[0] / p0 : 1, np1 = walk == 3 ? lat.L[1] / p1 : 1;
-  for (int64_t pos = first; pos < count; pos += step) {
-    int64_t site0;
-    if (walk == 3) {
-      int64_t t = pos;
-      const int q = static_cast<int>(t % tp); t /= tp;
-      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
-      const int64_t patch = t * 8 + xcd;
-      const int pa = static_cast<int>(patch % np0), pb = static_cast<int>((patch / np0) % np1);
-      const int pc = static_cast<int>(patch / (static_cast<int64_t>(np0) * np1));
-      const int a = q % pt0, x1l = (q / pt0) % p1, x2l = q / (pt0 * p1);
-      site0 = (pa * p0 + a * SPB) + (pb * p1 + x1l) * lat.stride[1] + (pc * p2 + x2l) * lat.stride[2] + x3 * lat.stride[3];
-    } else if (walk == 2) {
-      int64_t t = pos;
-      const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
-      const int x1 = xcd * w1 + static_cast<int>(t % w1); t /= w1;
-      const int x2l = static_cast<int>(t % c2); t /= c2;
-      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
-      const int x2 = static_cast<int>(t) * c2 + x2l;
-      site0 = a * SPB + x1 * lat.stride[1] + x2 * lat.stride[2] + x3 * lat.stride[3];
-    } else if (walk == 1) {
-      int64_t t = pos;
-      const int a = static_cast<int>(t % tiles_x0); t /= tiles_x0;
-      const int x1 = static_cast<int>(t % lat.L[1]); t /= lat.L[1];
-      const int x2l = static_cast<int>(t % c2); t /= c2;
-      const int x3 = static_cast<int>(t % lat.L[3]); t /= lat.L[3];
-      const int x2 = static_cast<int>(t) * c2 + x2l;
-      site0 = a * SPB + x1 * lat.stride[1] + x2 * lat.stride[2] + x3 * lat.stride[3];
-    } else {
-      site0 = pos * SPB;
-    }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t site0 = tile * SPB;
     __syncthreads();
     // ---- stage links: thread e = (site s, mu, dir) copies one 3x3 link
-    if (tid < SPB * lat.ndim * 2 && !((flags & 32) && pos != first)) {  // flag 32: ablation, stage links once
+    if (tid < SPB * lat.ndim * 2) {
       const int dir = tid & 1;
       const int mu = (tid >> 1) % lat.ndim;
       const int s = (tid >> 1) / lat.ndim;
@@ -532,13 +480,8 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
           else src = Ughost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 9;
         }
         double2* dst = Us + ((s * 4 + mu) * 2 + dir) * 9;
-        if (flags & 4) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) dst[k] = ld_nt(src + k);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) dst[k] = src[k];
-        }
+        for (int k = 0; k < 9; ++k) dst[k] = src[k];
       }
     }
     __syncthreads();
@@ -560,23 +503,11 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
         if (x[mu] > 0) pb = in + (site - lat.stride[mu]) * 3 * M;
         else if (!lat.split[mu]) pb = in + (site + (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
         else pb = ghost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 3 * M;
-        if (flags & 16) {  // ablation: perfect locality, every neighbour is the site itself
-          pf = in + site * 3 * M;
-          pb = pf;
-        }
         double2 f[3], bk[3];
-        if ((flags & 2) && mu == 3) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            f[k] = ld_nt(pf + k * M + j);
-            bk[k] = ld_nt(pb + k * M + j);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            f[k] = pf[k * M + j];
-            bk[k] = pb[k * M + j];
-          }
+        for (int k = 0; k < 3; ++k) {
+          f[k] = pf[k * M + j];
+          bk[k] = pb[k * M + j];
         }
         const double2* uf = Us + ((sl * 4 + mu) * 2 + 0) * 9;
         const double2* ub = Us + ((sl * 4 + mu) * 2 + 1) * 9;
@@ -607,19 +538,12 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
       const int64_t o = (site * 3 + r) * M + j;
       if (MODE == HOP_PLAIN) {
         tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
-        if (ok) {
-          if (flags & 1) st_nt(out + o, tv[r]);
-          else out[o] = tv[r];
-        }
+        if (ok) out[o] = tv[r];
       } else {
-        pv[r] = ok ? ((flags & 8) ? ld_nt(p + o) : p[o]) : make_double2(0.0, 0.0);
+        pv[r] = ok ? p[o] : make_double2(0.0, 0.0);
         tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-        if (ok) {
-          if (flags & 1) st_nt(out + o, tv[r]);
-          else out[o] = tv[r];
-        } else {
-          tv[r] = make_double2(0.0, 0.0);
-        }
+        if (ok) out[o] = tv[r];
+        else tv[r] = make_double2(0.0, 0.0);
       }
     }
     if (GRAM) {
@@ -630,14 +554,6 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
   if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Stencil, specialised: ndim = 4, L0 a multiple of the tile (SPB consecutive x0 sites), local volume
-// < 2^31 sites.  Everything that is uniform over a tile -- its coordinates, the six x1/x2/x3
-// neighbour tiles, their ghost redirection, the staggered phases -- is scalar work done once per tile
-// in 32-bit arithmetic; only the +-x0 neighbours need per-lane selects.  The 2*4 links of the tile's
-// sites are fetched one tile ahead by all 256 threads (forward links of a tile are one contiguous 9 KB
-// run; U_0(x-0) is the forward link of the previous site), parked in registers during the compute of
-// the current tile and written to the other half of a double-buffered LDS image: one barrier per tile.
 // ---------------------------------------------------------------------------------------------------
 struct TileGeom {
   int x0b, x1, x2, x3;   // coordinates of the tile's first site
@@ -1075,28 +991,18 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, int c2, int walk, int flags, int p0, int p1, int p2) {
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune) {
   const int spb = 4 * (64 / m);
   // specialised 4-D kernel: tile = spb consecutive x0 sites of one row, 32-bit site arithmetic
-  if (!(flags & 64) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3]) {
-    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
-    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
-    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, max_blocks, walk, p0, p1, p2, flags);
+  if (lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3]) {
+    const int walk = tune.patch_walk ? 3 : 0, flags = tune.nontemporal ? 1 : 0;
+    const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
+    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
+    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
+    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
   }
-  if (walk == 3) {
-    const bool ok3 = lat.ndim == 4 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % spb == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
-                     lat.L[2] % p2 == 0 && ((lat.L[0] / p0) * (lat.L[1] / p1) * (lat.L[2] / p2)) % 8 == 0 && max_blocks % 8 == 0;
-    if (!ok3) walk = 2;
-  }
-  const bool blockable = lat.ndim == 4 && lat.L[0] % spb == 0 && c2 > 0 && lat.L[2] % c2 == 0;
-  if (walk == 2 && !(blockable && lat.L[1] % 8 == 0 && max_blocks % 8 == 0)) walk = blockable ? 1 : 0;
-  if (walk == 1 && !blockable) walk = 0;
-  const int64_t ntiles = walk > 0 ? lat.V / spb : (lat.V + spb - 1) / spb;
-  int grid = grid_tiles(ntiles, 1, max_blocks);
-  if (walk >= 2) {
-    grid &= ~7;
-    if (grid < 8) { walk = blockable ? 1 : 0; grid = grid_tiles(ntiles, 1, max_blocks); }
-  }
+  const int64_t ntiles = (lat.V + spb - 1) / spb;
+  const int grid = grid_tiles(ntiles, 1, max_blocks);
   const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
@@ -1104,14 +1010,14 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
   {                                                                                                                         \
     if (mode == HOP_PLAIN)                                                                                                  \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
-                         p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);                                                                \
+                         p, c0, partials, ntiles);                                                                          \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_hop_fast<MM, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost,    \
-                         out, p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);                                                           \
+                         out, p, c0, partials, ntiles);                                                                     \
   }
   if (gram && m == 16 && mode == HOP_SHIFTED) {
     hipLaunchKernelGGL((k_hop_fast<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out,
-                       p, c0, partials, ntiles, c2, walk, flags, p0, p1, p2);
+                       p, c0, partials, ntiles);
   } else if (m == 8) BCG_HOP(8) else if (m == 16) BCG_HOP(16) else BCG_HOP(32)
 #undef BCG_HOP
   return grid;

@@ -21,9 +21,17 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
                      int max_blocks);
+// Tuning of the specialised 4-D stencil (defaults chosen by measurement at 64^4, m = 16).
+struct HopTuning {
+  bool patch_walk = true;        // per-XCD patches swept along x3 (false: lexicographic tile order)
+  int patch[3] = {16, 8, 8};     // patch extents in x0, x1, x2
+  int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
+  bool nontemporal = true;       // stream `out` (and p) past L2
+};
+
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, int c2, int walk, int flags, int p0, int p1, int p2);
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune);
 
 }  // namespace bcg

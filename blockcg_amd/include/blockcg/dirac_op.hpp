@@ -13,10 +13,12 @@ class dirac_op {
   int V;        // :25
   double mass;  // :26
 
-  explicit dirac_op(int V_, double mass_ = 0.1) : V(V_), mass(mass_), lat_(&blockcg::lattice::one_dimensional(V_)) {
-    create();
+  explicit dirac_op(int V_, double mass_ = 0.1) : V(V_), mass(mass_), lat_(nullptr) {
     std::vector<blockcg::cmatrix<N_f, N_f>> U(V);
-    for (int ix = 0; ix < V; ++ix) U[ix].setRandom();  // :28-31
+    for (int ix = 0; ix < V; ++ix) U[ix].setRandom();  // :28-31, drawn before anything touches the GPU runtime
+    lat_ = &blockcg::lattice::one_dimensional(V_);
+    create();
+    blockcg::rand_state_guard keep_callers_rand_sequence;
     blockcg::check(bcg_gauge_upload(g_, reinterpret_cast<const double*>(U.data())), lat_->ctx(), "bcg_gauge_upload");
   }
   // n-D: links i.i.d. uniform [-1,1) from the counter-based device generator
@@ -45,7 +47,10 @@ class dirac_op {
   blockcg::lattice& lat() const { return *lat_; }
 
  private:
-  void create() { blockcg::check(bcg_gauge_create(lat_->ctx(), &g_), lat_->ctx(), "bcg_gauge_create"); }
+  void create() {
+    blockcg::rand_state_guard keep_callers_rand_sequence;
+    blockcg::check(bcg_gauge_create(lat_->ctx(), &g_), lat_->ctx(), "bcg_gauge_create");
+  }
   blockcg::lattice* lat_;
   bcg_gauge* g_ = nullptr;
 };

@@ -12,6 +12,8 @@
 // block_fermion_field<N>(blockcg::lattice&).
 #ifndef BLOCKCG_FIELDS_HPP
 #define BLOCKCG_FIELDS_HPP
+#include <stdlib.h>
+
 #include <complex>
 #include <map>
 #include <memory>
@@ -28,12 +30,33 @@ inline void check(int rc, const bcg_context* ctx, const char* what) {
   if (rc != BCG_OK) throw std::runtime_error(std::string(what) + ": " + bcg_last_error(ctx));
 }
 
+// The reference draws its links and sources from std::rand() (inc/dirac_op.hpp:28-31, inc/fields.hpp:62-66), and
+// a driver that calls srand(k) expects the same lattice from these headers.  The GPU runtime, however, consumes
+// rand() values of its own while it initialises (observed: B differs from run to run).  While an object of this
+// class lives, rand()/random() run on a private state; the caller's sequence continues untouched afterwards
+// (glibc's rand() shares random()'s state, which initstate/setstate swap).
+class rand_state_guard {
+ public:
+  rand_state_guard() { prev_ = initstate(0x5eed, scratch(), 256); }
+  ~rand_state_guard() { setstate(prev_); }
+  rand_state_guard(const rand_state_guard&) = delete;
+  rand_state_guard& operator=(const rand_state_guard&) = delete;
+
+ private:
+  static char* scratch() {
+    static char st[256];
+    return st;
+  }
+  char* prev_;
+};
+
 // One GPU's (sub-)lattice: owns the bcg_context.
 class lattice {
  public:
   explicit lattice(const std::vector<int>& dims, int device = 0, const std::vector<int>& grid = {},
                    const std::vector<int>& coords = {}, void* stream = nullptr)
       : dims_(dims) {
+    rand_state_guard keep_callers_rand_sequence;
     check(bcg_context_create(&ctx_, device, stream, static_cast<int>(dims.size()), dims.data(),
                              grid.empty() ? nullptr : grid.data(), coords.empty() ? nullptr : coords.data()),
           nullptr, "bcg_context_create");
@@ -78,6 +101,7 @@ class block_fermion_field {
   block_fermion_field(const block_fermion_field& o) : V(o.V), lat_(o.lat_) {  // deep copy, value semantics
     alloc();
     o.flush();
+    blockcg::rand_state_guard keep_callers_rand_sequence;
     blockcg::check(bcg_field_copy(f_, o.f_), lat_->ctx(), "bcg_field_copy");
   }
   block_fermion_field& operator=(const block_fermion_field& o) {
@@ -182,6 +206,7 @@ class block_fermion_field {
   blockcg::lattice& lat() const { return *lat_; }
   void flush() const {  // make the device copy current
     if (host_dirty_) {
+      blockcg::rand_state_guard keep_callers_rand_sequence;
       blockcg::check(bcg_field_upload(f_, reinterpret_cast<const double*>(host_.data())), lat_->ctx(), "upload");
       host_dirty_ = false;
     }
@@ -189,7 +214,10 @@ class block_fermion_field {
   void device_written() { host_valid_ = host_dirty_ = false; }  // a kernel overwrote the device copy
 
  private:
-  void alloc() { blockcg::check(bcg_field_create(lat_->ctx(), N_rhs, &f_), lat_->ctx(), "bcg_field_create"); }
+  void alloc() {
+    blockcg::rand_state_guard keep_callers_rand_sequence;
+    blockcg::check(bcg_field_create(lat_->ctx(), N_rhs, &f_), lat_->ctx(), "bcg_field_create");
+  }
   void pull() const {
     if (!host_valid_) {
       host_.resize(V);

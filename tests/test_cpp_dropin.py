@@ -69,24 +69,23 @@ def test_reference_unit_test_against_headers(built):
 @pytest.mark.gpu
 def test_benchmark_driver_matches_reference_run(built):
     """`./benchmark 100 0.1 1e-10` of the unmodified reference (built here from /root/reference) printed
-    SBCGrQ_iterations 360 (= 12 x 30 block iterations) and a shift-0 residual of 6.416677e-11; same default
-    rand() seed, same lattice.  The stopping test compares an ESTIMATED residual with eps, and at this
-    configuration the estimate after 30 iterations sits right at 1e-10, so rounding decides between 30 and 31
-    iterations (parity definition: iteration count +-1); with 30 the printed residuals must match the reference's."""
-    r = subprocess.run([built["bench"], "100", "0.1", "1e-10"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    it = int(re.search(r"SBCGrQ_iterations:\s+(\d+)", r.stdout).group(1))
-    assert it in (348, 360, 372)
-    # SCG column of the same run of the reference: SCG_iterations 2142, residuals 9.834652e-11 ...
-    it_scg = int(re.search(r"SCG_iterations:\s+(\d+)", r.stdout).group(1))
-    assert abs(it_scg - 2142) <= 24  # 12 columns of ~178 iterations each; +-2 per column from rounding at the threshold
-    res_scg = [float(x) for x in re.search(r"SCG residuals:\s+(.*)", r.stdout).group(1).split()]
-    assert len(res_scg) == 9 and max(res_scg) < 2e-10
-    res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
-    assert len(res) == 9 and res[0] < 2e-10
+      SCG residuals 9.834652e-11 ..., SBCGrQ residuals 6.416677e-11 ..., SCG_iterations 2142, SBCGrQ_iterations 360.
+    The driver built on the drop-in headers draws the same lattice and sources from std::rand() (the headers keep the
+    GPU runtime off the caller's rand() sequence), so it must reproduce that run up to rounding: identical block
+    iteration count, SCG within one iteration per column, residuals of the same size; and two runs must agree bitwise."""
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([built["bench"], "100", "0.1", "1e-10"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1]
+    out = outs[0]
+    assert int(re.search(r"SBCGrQ_iterations:\s+(\d+)", out).group(1)) == 360
+    assert abs(int(re.search(r"SCG_iterations:\s+(\d+)", out).group(1)) - 2142) <= 12
+    res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", out).group(1).split()]
     ref = [6.416677e-11, 6.416697e-11, 6.416718e-11, 6.416649e-11, 6.414947e-11, 6.399223e-11, 6.245456e-11, 7.270243e-12,
            2.186446e-15]
-    if it == 360:
-        assert np.allclose(res[:8], ref[:8], rtol=2e-2)
-    else:
-        assert all(a < 2e-10 for a in res)
+    assert len(res) == 9 and np.allclose(res[:8], ref[:8], rtol=0.15)
+    res_scg = [float(x) for x in re.search(r"SCG residuals:\s+(.*)", out).group(1).split()]
+    ref_scg = [9.834652e-11, 9.834652e-11, 9.834590e-11, 9.834536e-11, 9.823971e-11, 9.728676e-11, 8.827295e-11]
+    assert len(res_scg) == 9 and np.allclose(res_scg[:7], ref_scg, rtol=0.05)
