@@ -16,10 +16,12 @@ c_size_p = ctypes.POINTER(ctypes.c_size_t)
 
 HALO_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p, c_size_p, c_size_p, c_size_p)
 ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+HALO_END_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 
 
 class bcg_comm(ctypes.Structure):
-    _fields_ = [("user", ctypes.c_void_p), ("halo_exchange", HALO_CB), ("allreduce_sum", ALLREDUCE_CB)]
+    _fields_ = [("user", ctypes.c_void_p), ("halo_exchange", HALO_CB), ("allreduce_sum", ALLREDUCE_CB),
+                ("halo_exchange_begin", HALO_CB), ("halo_exchange_end", HALO_END_CB)]
 
 
 class bcg_sbcgrq_trace(ctypes.Structure):

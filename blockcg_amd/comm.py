@@ -54,6 +54,16 @@ def halo_plan(dims, grid, coords, site_bytes):
     return [(ps[k], pr[k], so[k], ro[k], nb[k]) for k in range(n)], ghost.value
 
 
+def post_messages(send, recv, msgs, group=None):
+    """Device-direct (RCCL) form split in two: post the batched sends/receives and return the work handles; the
+    caller waits on them later (TorchDistComm._halo_end), so independent kernels enqueued in between overlap."""
+    ops = []
+    for ps, pr, so, ro, nb in msgs:
+        ops.append(dist.P2POp(dist.isend, send[so:so + nb], ps, group))
+        ops.append(dist.P2POp(dist.irecv, recv[ro:ro + nb], pr, group))
+    return dist.batch_isend_irecv(ops)
+
+
 def exchange_messages(send, recv, msgs, group=None, direct=False, sync=None):
     """Move the faces of one halo exchange.  send/recv: flat uint8 tensors (device memory when `direct`,
     i.e. backend nccl = RCCL; otherwise staged through host memory for gloo).  Messages to the same peer
@@ -94,7 +104,7 @@ class _DevMem:
 class TorchDistComm:
     """Owns the HIP stream the context enqueues on and implements bcg_comm with torch.distributed."""
 
-    def __init__(self, device_index=0, group=None):
+    def __init__(self, device_index=0, group=None, overlap=True):
         self.group = group
         self.device = torch.device("cuda", device_index)
         self.backend = dist.get_backend(group)
@@ -105,7 +115,14 @@ class TorchDistComm:
         self.error = None
         self._halo_cb = _lib.HALO_CB(self._halo)
         self._allreduce_cb = _lib.ALLREDUCE_CB(self._allreduce)
-        self.struct = _lib.bcg_comm(None, self._halo_cb, self._allreduce_cb)
+        self._begin_cb = _lib.HALO_CB(self._halo_begin)
+        self._end_cb = _lib.HALO_END_CB(self._halo_end)
+        self._pending = []
+        self.overlap = overlap
+        if overlap:
+            self.struct = _lib.bcg_comm(None, self._halo_cb, self._allreduce_cb, self._begin_cb, self._end_cb)
+        else:
+            self.struct = _lib.bcg_comm(None, self._halo_cb, self._allreduce_cb, _lib.HALO_CB(), _lib.HALO_END_CB())
 
     @property
     def stream_ptr(self):
@@ -135,6 +152,34 @@ class TorchDistComm:
                 exchange_messages(send, recv, msgs, self.group, self.direct, sync=self.stream.synchronize)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+    def _halo_begin(self, user, n, peer_s, peer_r, off_s, off_r, nbytes):
+        """Post the exchange; with RCCL the stream is not made to wait here (see _halo_end)."""
+        try:
+            sp, rp, each = self.ctx.halo_buffers()
+            send = self._view(sp, each)
+            recv = self._view(rp, each)
+            msgs = [(peer_s[k], peer_r[k], off_s[k], off_r[k], nbytes[k]) for k in range(n)]
+            with torch.cuda.stream(self.stream):
+                if self.direct:
+                    self._pending = post_messages(send, recv, msgs, self.group)
+                else:  # host-staged transport has nothing to overlap: do it all now
+                    exchange_messages(send, recv, msgs, self.group, False, sync=self.stream.synchronize)
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def _halo_end(self, user):
+        try:
+            with torch.cuda.stream(self.stream):
+                for w in self._pending:
+                    w.wait()  # the context's stream waits for the exchange; the host does not block
+            self._pending = []
+            return 0
+        except Exception as e:
             self.error = e
             return 1
 

@@ -118,7 +118,7 @@ int ensure_halo(bcg_context* c, size_t bytes) {
   return BCG_OK;
 }
 
-constexpr int kMaxGramBlocks = 1024;
+constexpr int kMaxGramBlocks = 2048;  // also covers interior + boundary stencil launches (2 x 1024)
 constexpr size_t kMatSlotBytes = 32 * 32 * sizeof(double2);
 constexpr int kMatSlots = 96;
 
@@ -227,19 +227,27 @@ int halo_plan(int ndim, const int* gdims, const int* grid, const int* coords, si
   return n;
 }
 
-// Post the face messages for `site_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).
-int exchange_faces(bcg_context* c, size_t site_bytes) {
+// Post the face messages for `site_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).  split = true uses the
+// begin half of the optional split form (the caller then issues exchange_end after the interior tiles).
+int exchange_faces(bcg_context* c, size_t site_bytes, bool split = false) {
   if (!c->have_comm || !c->comm.halo_exchange) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
   int peer_s[8], peer_r[8];
   size_t off_s[8], off_r[8], nb[8];
   const int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
   if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
-  if (c->comm.halo_exchange(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0)
-    BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
+  auto fn = split ? c->comm.halo_exchange_begin : c->comm.halo_exchange;
+  if (fn(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0) BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
+  return BCG_OK;
+}
+inline bool can_overlap(const bcg_context* c) {
+  return c->distributed && c->have_comm && c->comm.halo_exchange_begin && c->comm.halo_exchange_end;
+}
+int exchange_end(bcg_context* c) {
+  if (c->comm.halo_exchange_end(c->comm.user) != 0) BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange_end callback failed");
   return BCG_OK;
 }
 
-int halo_field(bcg_context* c, const bcg_field* f) {
+int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
   if (!c->distributed) return BCG_OK;
   const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
   BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
@@ -248,8 +256,8 @@ int halo_field(bcg_context* c, const bcg_field* f) {
     bcg::launch_pack_faces(c->stream, f->m, c->lat, f->d, c->halo_send);
   }
   BCG_TRY(check_launch(c, "pack_faces"));
-  ProfScope ps(c, "halo_exchange");
-  return exchange_faces(c, site_bytes);
+  ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
+  return exchange_faces(c, site_bytes, split);
 }
 
 int halo_gauge(bcg_context* c, bcg_gauge* g) {
@@ -278,18 +286,45 @@ constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
 int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
         double c0, int* gram_blocks = nullptr) {
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
-  BCG_TRY(halo_field(c, in));
   const int m = in->m;
   if (gram_blocks) *gram_blocks = 0;
-  if (fast_hop(c, m)) {
-    const bool gram = gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
-    if (gram) BCG_TRY(ensure_scratch(c));
-    ProfScope ps(c, gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted"));
+  const bool fast = fast_hop(c, m);
+  const bool gram = fast && gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
+  const char* name = gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
+  if (gram) BCG_TRY(ensure_scratch(c));
+  if (fast && can_overlap(c) && bcg::hop_can_split_tiles(m, c->lat)) {
+    // pack -> post the exchange -> interior tiles (no ghost reads) -> wait for the exchange -> boundary tiles
+    BCG_TRY(halo_field(c, in, /*split=*/true));
+    bcg::HopTuning tune = c->hop_tune;
+    tune.blocks = tune.blocks_overlap;  // leave some CUs to the transport's kernels while it runs
+    int nb1, nb2;
+    {
+      ProfScope ps(c, name);
+      nb1 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+                                 p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, /*interior*/ 1);
+    }
+    BCG_TRY(check_launch(c, name));
+    {
+      ProfScope ps(c, "halo_exchange_end");
+      BCG_TRY(exchange_end(c));
+    }
+    {
+      ProfScope ps(c, "hop_boundary");
+      nb2 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+                                 p ? p->d : nullptr, c0, gram ? c->partials + static_cast<size_t>(nb1) * m * m : c->partials,
+                                 gram, kFastBlocks, c->hop_tune, /*boundary*/ 2);
+    }
+    if (gram) *gram_blocks = nb1 + nb2;
+    return check_launch(c, "hop_boundary");
+  }
+  BCG_TRY(halo_field(c, in));
+  if (fast) {
+    ProfScope ps(c, name);
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune);
+                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune, 0);
     if (gram) *gram_blocks = nb;
   } else {
-    ProfScope ps(c, mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
+    ProfScope ps(c, name);
     bcg::launch_hop_generic(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                             p ? p->d : nullptr, c0);
   }

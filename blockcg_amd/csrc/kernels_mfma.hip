@@ -649,7 +649,9 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
 // Measured on one device (tools/ab_bench.sh): carrying the -x3 neighbours / U_3(x-3) across steps pays for the
 // fused-Gram variant (15.6 -> 13.8 ms at 64^4) but not for the plain hop (11.7 -> 13.0 ms), and asking for a minimum
 // of 2 waves per SIMD in __launch_bounds__ costs 1.5 ms on both, so: CARRY = GRAM, plain __launch_bounds__(256).
-template <int M, int MODE, bool GRAM, bool NT>
+// CLS selects the tiles a launch processes: 0 all, 1 interior only (no site of the tile reads a ghost), 2 boundary only.
+// Interior and boundary launches bracket the halo exchange so that it overlaps the interior arithmetic.
+template <int M, int MODE, bool GRAM, bool NT, int CLS>
 __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                               const double2* __restrict__ ghost, double2* __restrict__ out,
@@ -722,13 +724,35 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
       fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
   }
 
+  // tile classes: a tile is "boundary" when one of its sites has a neighbour in a ghost face
+  auto wanted = [&](const TileGeom& t) -> bool {
+    if (CLS == 0) return true;
+    const bool bnd = (sp0 && (t.x0b == 0 || t.x0b + SPB == L0)) || (sp1 && (t.x1 == 0 || t.x1 == L1 - 1)) ||
+                     (sp2 && (t.x2 == 0 || t.x2 == L2 - 1)) || (sp3 && (t.x3 == 0 || t.x3 == L3 - 1));
+    return bnd == (CLS == 2);
+  };
+  // advance (dg, left) to the next wanted tile; false when the block's sequence is exhausted
+  auto next_tile = [&](TileGeom& t) -> bool {
+    while (left > 0) {
+      digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
+      --left;
+      t = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+      if (wanted(t)) return true;
+    }
+    return false;
+  };
   TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
-  if (left > 0) BCG_FETCH_LINKS(g, false)
+  bool have = left > 0;
+  if (have) {
+    --left;  // `left` now counts the positions after the current one
+    if (!wanted(g)) have = next_tile(g);
+  }
+  if (have) BCG_FETCH_LINKS(g, false)
   int stage = 0;
   int site_m1 = -1;          // site0 of the previous tile of this block
   int fsite_m1 = -1, fsite_m2 = -1;  // first site of the +x3 neighbour tile loaded 1 and 2 steps ago (-1: ghost)
   bool carry_u3 = false;     // this tile's U_3(x-3) is the previous tile's forward link
-  for (unsigned it = 0; it < left; ++it) {
+  while (have) {
     {  // park the links fetched for this tile in the current LDS stage
       dv2* Lf = reinterpret_cast<dv2*>(Ls + stage * STAGE);
       dv2* Lb = Lf + NF;
@@ -751,9 +775,8 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     __syncthreads();
     const TileGeom cur = g;
     const bool cur_carry_u3 = carry_u3;
-    if (it + 1 < left) {  // prefetch the next tile's links; they land while this tile computes
-      digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
-      g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+    have = next_tile(g);
+    if (have) {  // prefetch the next tile's links; they land while this tile computes
       carry_u3 = CARRY && g.x3 > 0 && g.site0 - S3 == cur.site0;
       BCG_FETCH_LINKS(g, carry_u3)
     }
@@ -887,6 +910,10 @@ void allow_lds(K kernel, size_t bytes) {
 
 bool mfma_width(int m) { return m == 16 || m == 32; }  // declared in kernels.hpp
 bool hop_fast_width(int m) { return m == 8 || m == 16 || m == 32; }
+bool hop_can_split_tiles(int m, const LatticeDev& lat) {
+  const int spb = 4 * (64 / m);
+  return hop_fast_width(m) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3];
+}
 int phaseC_max_shifts(int m) { return m == 16 ? 8 : (m == 32 ? 1 : 0); }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
@@ -959,7 +986,7 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
 template <int M>
 static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
                        const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
-                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int flags) {
+                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int flags, int cls) {
   constexpr int SPB = 4 * (64 / M);
   const int ntiles = static_cast<int>(lat.V / SPB);
   const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
@@ -971,36 +998,40 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
-#define BCG_LAUNCH4(MM, MD, GR, NTV)                                                                                     \
+  (void)flags;  // the streaming (non-temporal) form is the only one instantiated
+#define BCG_LAUNCH4(MM, MD, GR, CL)                                                                                      \
   do {                                                                                                                   \
-    allow_lds(k_hop4<MM, MD, GR, NTV>, lds);                                                                             \
-    hipLaunchKernelGGL((k_hop4<MM, MD, GR, NTV>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0, \
-                       partials, ntiles, hw, flags);                                                                     \
+    allow_lds(k_hop4<MM, MD, GR, true, CL>, lds);                                                                        \
+    hipLaunchKernelGGL((k_hop4<MM, MD, GR, true, CL>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                       c0, partials, ntiles, hw, flags);                                                                 \
   } while (0)
-  const bool nt = (flags & 1) != 0;
-  if (gram && M == 16 && mode == HOP_SHIFTED) {
-    if (nt) BCG_LAUNCH4(16, HOP_SHIFTED, true, true); else BCG_LAUNCH4(16, HOP_SHIFTED, true, false);
-  } else if (mode == HOP_PLAIN) {
-    if (nt) BCG_LAUNCH4(M, HOP_PLAIN, false, true); else BCG_LAUNCH4(M, HOP_PLAIN, false, false);
-  } else {
-    if (nt) BCG_LAUNCH4(M, HOP_SHIFTED, false, true); else BCG_LAUNCH4(M, HOP_SHIFTED, false, false);
-  }
+#define BCG_LAUNCH4_CLS(MM, MD, GR)                 \
+  do {                                              \
+    if (cls == 1) BCG_LAUNCH4(MM, MD, GR, 1);       \
+    else if (cls == 2) BCG_LAUNCH4(MM, MD, GR, 2);  \
+    else BCG_LAUNCH4(MM, MD, GR, 0);                \
+  } while (0)
+  if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4_CLS(16, HOP_SHIFTED, true);
+  else if (mode == HOP_PLAIN) BCG_LAUNCH4_CLS(M, HOP_PLAIN, false);
+  else BCG_LAUNCH4_CLS(M, HOP_SHIFTED, false);
+#undef BCG_LAUNCH4_CLS
 #undef BCG_LAUNCH4
   return grid;
 }
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, const HopTuning& tune) {
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class) {
   const int spb = 4 * (64 / m);
   // specialised 4-D kernel: tile = spb consecutive x0 sites of one row, 32-bit site arithmetic
-  if (lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3]) {
+  if (hop_can_split_tiles(m, lat)) {
     const int walk = tune.patch_walk ? 3 : 0, flags = tune.nontemporal ? 1 : 0;
     const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
-    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
-    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
-    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags);
+    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
+    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
+    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
   }
+  if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles
   const int64_t ntiles = (lat.V + spb - 1) / spb;
   const int grid = grid_tiles(ntiles, 1, max_blocks);
   const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;

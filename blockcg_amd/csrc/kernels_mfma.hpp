@@ -26,12 +26,15 @@ struct HopTuning {
   bool patch_walk = true;        // per-XCD patches swept along x3 (false: lexicographic tile order)
   int patch[3] = {16, 8, 8};     // patch extents in x0, x1, x2
   int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
-  bool nontemporal = true;       // stream `out` (and p) past L2
+  bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
+  int blocks_overlap = 480;      // grid of the interior launch while a halo exchange is in flight: leaves CUs for RCCL
 };
 
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, const HopTuning& tune);
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class);
+// true when launch_hop_fast can process interior (tile_class 1) and boundary (2) tiles in separate launches
+bool hop_can_split_tiles(int m, const LatticeDev& lat);
 
 }  // namespace bcg

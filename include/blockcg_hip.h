@@ -67,6 +67,13 @@ typedef struct bcg_comm {
   int (*halo_exchange)(void* user, int n_msgs, const int* peer_send, const int* peer_recv, const size_t* send_offset,
                        const size_t* recv_offset, const size_t* nbytes);
   int (*allreduce_sum)(void* user, void* buf, size_t count);
+  /* Optional split form of halo_exchange (both NULL or both set).  begin posts the same messages, ordered after the
+   * work already enqueued on the context's stream, and returns without making the stream wait; end makes the stream
+   * wait for their completion.  Between the two the library enqueues the stencil over the interior tiles, which read
+   * no ghost site, so the exchange overlaps that arithmetic; the boundary tiles follow end. */
+  int (*halo_exchange_begin)(void* user, int n_msgs, const int* peer_send, const int* peer_recv, const size_t* send_offset,
+                             const size_t* recv_offset, const size_t* nbytes);
+  int (*halo_exchange_end)(void* user);
 } bcg_comm;
 
 /* ---- context ------------------------------------------------------------------------------- */

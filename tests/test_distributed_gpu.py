@@ -63,6 +63,17 @@ with torch.cuda.stream(s):
     exchange_messages(send, recv, [(0, 0, 0, 1024, 2048), (0, 0, 2048, 8192, 4096)], None, direct=True)
 s.synchronize()
 assert torch.equal(dst[1024:3072], send[0:2048]) and torch.equal(dst[8192:12288], send[2048:6144])
+# split form used for the overlap: post, enqueue independent work, then make the stream wait
+from blockcg_amd.comm import post_messages
+dst.zero_()
+with torch.cuda.stream(s):
+    works = post_messages(send, recv, [(0, 0, 0, 4096, 1024)], None)
+    filler = torch.ones(1 << 20, device="cuda").sum()
+    for w in works:
+        w.wait()
+    got = dst[4096:5120].clone()
+s.synchronize()
+assert torch.equal(got, send[0:1024]) and float(filler) == float(1 << 20)
 dist.destroy_process_group()
 print("RCCL_VIEW_OK")
 '''
