@@ -138,6 +138,8 @@ class TorchDistComm:
         if t is None:
             mem = _DevMem(ptr, nbytes, "<f8", 8) if f64 else _DevMem(ptr, nbytes)
             t = torch.as_tensor(mem, device=self.device)
+            if t.data_ptr() != ptr:  # must alias the library's buffer, never a copy
+                raise RuntimeError("torch did not alias the library's device buffer")
             self._views = {k: v for k, v in self._views.items() if k[2] != f64 or k[0] != ptr}
             self._views[key] = t
         return t

@@ -33,7 +33,7 @@ def built():
     if not os.path.exists(blockcg_amd.LIB_PATH):
         blockcg_amd.build()
     return {"test": _compile(os.path.join(ROOT, "examples", "test_solvers.cpp"), "test_solvers"),
-            "bench": _compile(os.path.join(ROOT, "examples", "benchmark.cpp"), "benchmark")}
+            "bench": _compile(os.path.join(ROOT, "examples", "solver_comparison.cpp"), "solver_comparison")}
 
 
 def test_headers_compile_with_host_compiler(built):
