@@ -303,7 +303,9 @@ struct ShiftPtrs {
   double2* P[8];
 };
 
-template <int M>
+// PREFETCH: load the next shift's P/X tiles while the current shift's MFMAs run (m = 16).  At m = 32 a tile is
+// 32 VGPRs, the prefetch would push the kernel to one wave per SIMD, and one launch takes a single shift anyway.
+template <int M, bool PREFETCH>
 __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
                                                 const double2* __restrict__ mats, int apply_rinv) {
   constexpr int NW = 4;
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restric
     }
     for (int s = 0; s < nshift; ++s) {
       Tile<M> pn, xn;
-      if (s + 1 < nshift) {  // prefetch the next shift's tiles while this one computes
+      if (PREFETCH && s + 1 < nshift) {  // prefetch the next shift's tiles while this one computes
         tile_load<M>(pn, sp.P[s + 1], row, kq, ok);
         tile_load<M>(xn, sp.X[s + 1], row, kq, ok);
       }
@@ -347,8 +349,13 @@ __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restric
       tile_from_acc<M>(p, AP);
       tile_store<M>(p, sp.P[s], row, kq, ok);
       if (s + 1 < nshift) {
-        p = pn;
-        x = xn;
+        if (PREFETCH) {
+          p = pn;
+          x = xn;
+        } else {
+          tile_load<M>(p, sp.P[s + 1], row, kq, ok);
+          tile_load<M>(x, sp.X[s + 1], row, kq, ok);
+        }
       }
     }
   }
@@ -944,13 +951,13 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   if (m == 16) {
     constexpr int M = 16;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
-    allow_lds(k_phaseC<M>, lds);
-    hipLaunchKernelGGL((k_phaseC<M>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    allow_lds(k_phaseC<M, true>, lds);
+    hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
-    allow_lds(k_phaseC<M>, lds);
-    hipLaunchKernelGGL((k_phaseC<M>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    allow_lds(k_phaseC<M, false>, lds);
+    hipLaunchKernelGGL((k_phaseC<M, false>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
   }
 }
 
