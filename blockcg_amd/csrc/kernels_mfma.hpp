@@ -27,7 +27,9 @@ struct HopTuning {
   int patch[3] = {16, 8, 8};     // patch extents in x0, x1, x2
   int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
-  int blocks_overlap = 480;      // grid of the interior launch while a halo exchange is in flight: leaves CUs for RCCL
+  int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
+                                 // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
+                                 // so CUs are not vacated for the transport; its kernels co-reside where registers allow
 };
 
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.

@@ -362,3 +362,54 @@ def test_other_solvers_on_4d_lattice_mfma_width(bc, orc):
         assert bc.true_residuals([X], B, D, [0.0]).max() < 2 * eps
         if it == ito:
             assert rel_err(X.download(), Xo) < TOL_SOLUTION
+
+
+def test_shift_retirement_matches_oracle(bc, orc):
+    """Shifts retire while the base system still iterates (eps_shifts >> eps): the reference decrements a counter
+    and stops updating the largest active shift (inc/block_solvers.hpp:161,179-181).  Same retirement iterations,
+    same frozen solutions."""
+    dims, m, mass = [12, 6, 4], 4, 0.05
+    shifts, eps, eps_s = [0.0, 0.3, 2.0, 9.0], 1e-10, 1e-4
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 81)
+    Bh = orc.fill_field(m, V, 82)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, U=U)
+    B = bc.block_fermion_field(ctx, m, Bh)
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    info = bc.SBCGrQ(X, B, D, shifts, eps, eps_s, trace_limit=400, return_info=True)
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, eps, eps_s, trace_limit=400)
+    assert abs(info["iterations"] - o["iterations"]) <= 1
+    n = min(info["iterations"], o["iterations"])
+    visited_gpu = info["trace"]["residual_shift"][:n] >= 0
+    visited_cpu = o["trace"]["residual_shift"][:n] >= 0
+    assert np.array_equal(visited_gpu, visited_cpu)          # every shift retires at the same iteration
+    assert not visited_cpu[-1, 1:].all()                     # and at least one did retire before the end
+    assert rel_err(np.stack([x.download() for x in X])[1:], o["X"][1:]) < 1e-9
+    res = bc.true_residuals(X, B, D, shifts)
+    assert res[0].max() < 2 * eps and res[1:].max() < 50 * eps_s
+
+
+@pytest.mark.parametrize("dims,m", [([1], 1), ([2], 3), ([3, 1, 2], 2), ([1, 1, 1, 1], 16), ([16, 1, 1, 2], 16), ([2, 2, 2, 2], 8)])
+def test_degenerate_lattices(bc, orc, dims, m):
+    """Extents of 1 and 2 (x+mu and x-mu coincide or are the site itself), single-site lattices, and
+    max_iterations = 0."""
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 91)
+    Bh = orc.fill_field(m, V, 92)
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, 0.7, U=U)
+    B = bc.block_fermion_field(ctx, m, Bh)
+    out = bc.block_fermion_field(ctx, m)
+    D.op(out, B)
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, 0.7, Bh)) < TOL_KERNEL
+    X = [bc.block_fermion_field(ctx, m).setRandom(seed=5)]
+    if 3 * V < m:  # more columns than rows: B cannot have full column rank, the initial CholQR (:115) breaks down.
+        with pytest.raises(bc.BlockCGError) as e:  # reported here; the reference would carry NaN
+            bc.SBCGrQ(X, B, D, [0.25], 1e-10, max_iterations=0)
+        assert e.value.code == 6
+        return
+    assert bc.SBCGrQ(X, B, D, [0.25], 1e-10, max_iterations=0) == 0
+    assert not X[0].download().any()                         # X is zeroed even when no iteration runs (:111-113)
+    it = bc.SBCGrQ(X, B, D, [0.25], 1e-10, max_iterations=200)
+    assert it <= 200 and bc.true_residuals(X, B, D, [0.25]).max() < 2e-10
