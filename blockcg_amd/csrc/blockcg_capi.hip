@@ -442,7 +442,7 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
   int nb;
   {
     ProfScope ps(c, "phaseB");
-    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, kFastBlocks);
+    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, c->row_blocks_B);
   }
   BCG_TRY(check_launch(c, "phaseB"));
   return finish_gram(c, m, nb, G2, true);
@@ -480,7 +480,7 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
     {
       ProfScope ps(c, "phaseC");
-      bcg::launch_phaseC(c->stream, m, rows_of(c), Q->d, Xp, Pp, ns, Md, first, kFastBlocks);
+      bcg::launch_phaseC(c->stream, m, rows_of(c), Q->d, Xp, Pp, ns, Md, first, c->row_blocks_C);
     }
     BCG_TRY(check_launch(c, "phaseC"));
   }
@@ -564,6 +564,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   }
   c->ghost_sites = ghost;
   // tuning overrides for experiments (tools/hop_sweep.py); defaults in kernels_mfma.hpp
+  if (const char* e = std::getenv("BCG_ROW_BLOCKS_B")) c->row_blocks_B = std::atoi(e);
+  if (const char* e = std::getenv("BCG_ROW_BLOCKS_C")) c->row_blocks_C = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_tune.patch_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_tune.blocks = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;

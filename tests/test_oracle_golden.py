@@ -125,3 +125,23 @@ def test_other_solvers_match_reference(orc):
     assert it == int(g["it_bcg"]) and rel_err(X, g["X_bcg"]) < TOL_SOLUTION
     X, it = orc.bcg(g["U"], dims, mass, g["B"], eps, with_qr=True)
     assert it == int(g["it_bcgrq"]) and rel_err(X, g["X_bcgrq"]) < TOL_SOLUTION
+
+
+def test_shift_retirement_against_live_reference(orc):
+    """eps_shifts >> eps: shifts retire early (inc/block_solvers.hpp:161,179-181).  Needs oracle/_ref (the unmodified
+    reference built from /root/reference); compares iteration count, frozen shifted solutions and residuals."""
+    import oracle
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    R = oracle.Reference(four_d=False)
+    V, m, mass = 96, 4, 0.05
+    shifts, eps, eps_s = [0.0, 0.3, 2.0, 9.0], 1e-10, 1e-4
+    U = R.make_dirac_1d(V, mass, 3)
+    B = R.field_random(m, V)
+    ref = R.sbcgrq(B, shifts, eps, eps_s)
+    got = orc.sbcgrq(U, [V], mass, B, shifts, eps, eps_s, trace_limit=2000)
+    assert got["iterations"] == ref["iterations"]
+    assert rel_err(got["X"], ref["X"]) < 1e-9
+    visited = got["trace"]["residual_shift"] >= 0
+    assert visited[0, 1:].all() and not visited[-1, 1:].all()   # all shifts start active, some retire before the end
+    assert rel_err(orc.true_residuals(U, [V], mass, B, shifts, got["X"]), R.true_residuals(B, shifts, ref["X"])) < 1e-6
