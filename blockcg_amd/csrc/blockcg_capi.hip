@@ -277,7 +277,8 @@ int halo_gauge(bcg_context* c, bcg_gauge* g) {
 // ---- building blocks ---------------------------------------------------------------------------
 bool same_shape(const bcg_field* a, const bcg_field* b) { return a && b && a->ctx == b->ctx && a->m == b->m; }
 
-inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }
+inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }       // + Gram, phase B
+inline bool fast_rmul(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_rows_width(m); }  // products, phase C
 inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
 constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
 
@@ -374,7 +375,7 @@ int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double
   BCG_TRY(upload_mat(c, M, &Md));
   {
     ProfScope ps(c, name);
-    if (fast_rows(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
+    if (fast_rmul(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
     else bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
   }
   return check_launch(c, name);
@@ -454,7 +455,7 @@ int trisolve(bcg_context* c, bcg_field* y, const CMat& R);
 int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, bcg_field* const* P, int n,
             const std::vector<CMat>& A, const std::vector<CMat>& Bm) {
   const int m = Q->m;
-  if (!fast_rows(c, m)) {
+  if (!fast_rmul(c, m)) {
     BCG_TRY(trisolve(c, Q, rho));
     for (int s = 0; s < n; ++s) {
       BCG_TRY(rmul(c, X[s], P[s], A[s], 0.0, bcg::RMUL_ADD, "block_axpy"));

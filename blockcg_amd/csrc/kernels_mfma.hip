@@ -117,34 +117,41 @@ __device__ __forceinline__ void tile_from_acc(Tile<M>& t, const Acc<M>& A) {
   }
 }
 
-// acc += in * C   (C staged in LDS at Ml).  M >= 16 (the re/im block of an output tile must not
-// depend on the lane).
+// acc += in * C   (C staged in LDS at Ml).  For M >= 16 the re/im block of an output tile is the same for all
+// lanes, so the choice between Re C and Im C and the sign are compile-time (the minus is the MFMA's NEG modifier).
+// For M = 8 one 16 x 16 tile holds both blocks: the A-operand lane picks its coefficient by its own output slot.
 template <int M>
 __device__ __forceinline__ void rmul_acc(Acc<M>& A, const Tile<M>& in, const double* Ml, int lane) {
-  static_assert(M == 16 || M == 32, "MFMA right-multiply is instantiated for m = 16, 32");
+  static_assert(M == 8 || M == 16 || M == 32, "MFMA right-multiply is instantiated for m = 8, 16, 32");
   constexpr int LD = MatLds<M>::LD;
   const int kq = lane >> 4;          // which of the 4 k-slots of a step this lane feeds (B operand)
   const int ar = lane & 15;          // A-operand row: output slot dr = kq_o + 4*reg_o
 #pragma unroll
-  for (int T = 0; T < M / 8; ++T) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int ri_o = (4 * T) / (M / 4);                          // lane independent for M >= 16
-    const int s_o = (4 * T + (ar >> 2)) % (M / 4);
+  for (int T = 0; T < (M + 7) / 8; ++T) {
+    const int q_o = 4 * T + (ar >> 2);                           // output slot index: ri_o*(M/4) + s_o
+    const int ri_o = q_o / (M / 4);                              // lane independent for M >= 16
+    const int s_o = q_o % (M / 4);
     const int j_o = 4 * s_o + (ar & 3);
     const double* base = Ml + kq * LD + 2 * j_o;                 // + s_i*4*LD + comp
 #pragma unroll
     for (int s_i = 0; s_i < M / 4; ++s_i) {
-      const double a_same = base[s_i * 4 * LD + 0 + 0];          // Re C(j_i, j_o)
+      const double a_same = base[s_i * 4 * LD + 0];              // Re C(j_i, j_o)
       const double a_cross = base[s_i * 4 * LD + 1];             // Im C(j_i, j_o)
-      if (ri_o == 0) {
-        // out_re += in_re * Re C - in_im * Im C
-        A.a[T] = mfma(a_same, in.v[s_i].x, A.a[T]);
-        A.a[T] = mfma_nega(a_cross, in.v[s_i].y, A.a[T]);
+      if (M >= 16) {
+        if ((4 * T) / (M / 4) == 0) {
+          // out_re += in_re * Re C - in_im * Im C
+          A.a[T] = mfma(a_same, in.v[s_i].x, A.a[T]);
+          A.a[T] = mfma_nega(a_cross, in.v[s_i].y, A.a[T]);
+        } else {
+          // out_im += in_re * Im C + in_im * Re C
+          A.a[T] = mfma(a_cross, in.v[s_i].x, A.a[T]);
+          A.a[T] = mfma(a_same, in.v[s_i].y, A.a[T]);
+        }
       } else {
-        // out_im += in_re * Im C + in_im * Re C
-        A.a[T] = mfma(a_cross, in.v[s_i].x, A.a[T]);
-        A.a[T] = mfma(a_same, in.v[s_i].y, A.a[T]);
+        const double c_re = ri_o ? a_cross : a_same;             // coefficient of in_re for this lane's output slot
+        const double c_im = ri_o ? a_same : -a_cross;            // coefficient of in_im
+        A.a[T] = mfma(c_re, in.v[s_i].x, A.a[T]);
+        A.a[T] = mfma(c_im, in.v[s_i].y, A.a[T]);
       }
     }
   }
@@ -158,25 +165,35 @@ __device__ __forceinline__ void rmul_acc2(Acc<M>& A1, const double* Ml1, Acc<M>&
   const int kq = lane >> 4;
   const int ar = lane & 15;
 #pragma unroll
-  for (int T = 0; T < M / 8; ++T) {
-    const int ri_o = (4 * T) / (M / 4);
-    const int s_o = (4 * T + (ar >> 2)) % (M / 4);
+  for (int T = 0; T < (M + 7) / 8; ++T) {
+    const int q_o = 4 * T + (ar >> 2);
+    const int ri_o = q_o / (M / 4);
+    const int s_o = q_o % (M / 4);
     const int j_o = 4 * s_o + (ar & 3);
     const int off = kq * LD + 2 * j_o;
 #pragma unroll
     for (int s_i = 0; s_i < M / 4; ++s_i) {
       const double a1s = Ml1[off + s_i * 4 * LD], a1c = Ml1[off + s_i * 4 * LD + 1];
       const double a2s = Ml2[off + s_i * 4 * LD], a2c = Ml2[off + s_i * 4 * LD + 1];
-      if (ri_o == 0) {
-        A1.a[T] = mfma(a1s, in.v[s_i].x, A1.a[T]);
-        A2.a[T] = mfma(a2s, in.v[s_i].x, A2.a[T]);
-        A1.a[T] = mfma_nega(a1c, in.v[s_i].y, A1.a[T]);
-        A2.a[T] = mfma_nega(a2c, in.v[s_i].y, A2.a[T]);
+      if (M >= 16) {
+        if ((4 * T) / (M / 4) == 0) {
+          A1.a[T] = mfma(a1s, in.v[s_i].x, A1.a[T]);
+          A2.a[T] = mfma(a2s, in.v[s_i].x, A2.a[T]);
+          A1.a[T] = mfma_nega(a1c, in.v[s_i].y, A1.a[T]);
+          A2.a[T] = mfma_nega(a2c, in.v[s_i].y, A2.a[T]);
+        } else {
+          A1.a[T] = mfma(a1c, in.v[s_i].x, A1.a[T]);
+          A2.a[T] = mfma(a2c, in.v[s_i].x, A2.a[T]);
+          A1.a[T] = mfma(a1s, in.v[s_i].y, A1.a[T]);
+          A2.a[T] = mfma(a2s, in.v[s_i].y, A2.a[T]);
+        }
       } else {
-        A1.a[T] = mfma(a1c, in.v[s_i].x, A1.a[T]);
-        A2.a[T] = mfma(a2c, in.v[s_i].x, A2.a[T]);
-        A1.a[T] = mfma(a1s, in.v[s_i].y, A1.a[T]);
-        A2.a[T] = mfma(a2s, in.v[s_i].y, A2.a[T]);
+        const double c1r = ri_o ? a1c : a1s, c1i = ri_o ? a1s : -a1c;
+        const double c2r = ri_o ? a2c : a2s, c2i = ri_o ? a2s : -a2c;
+        A1.a[T] = mfma(c1r, in.v[s_i].x, A1.a[T]);
+        A2.a[T] = mfma(c2r, in.v[s_i].x, A2.a[T]);
+        A1.a[T] = mfma(c1i, in.v[s_i].y, A1.a[T]);
+        A2.a[T] = mfma(c2i, in.v[s_i].y, A2.a[T]);
       }
     }
   }
@@ -921,7 +938,8 @@ bool hop_can_split_tiles(int m, const LatticeDev& lat) {
   const int spb = 4 * (64 / m);
   return hop_fast_width(m) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3];
 }
-int phaseC_max_shifts(int m) { return m == 16 ? 8 : (m == 32 ? 1 : 0); }
+bool mfma_rows_width(int m) { return m == 8 || m == 16 || m == 32; }  // right-multiply kernels (phase C, K5, K6)
+int phaseC_max_shifts(int m) { return (m == 16 || m == 8) ? 8 : (m == 32 ? 1 : 0); }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
                   double2* partials, int max_blocks) {
@@ -948,7 +966,11 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   }
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
   const int nmat = 1 + 2 * nshift;
-  if (m == 16) {
+  if (m == 8) {
+    constexpr int M = 8;
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
+    hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+  } else if (m == 16) {
     constexpr int M = 16;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
     allow_lds(k_phaseC<M, true>, lds);
@@ -972,7 +994,7 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
     else if (mode == RMUL_XPAY) hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_XPAY>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b); \
     else hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_MUL>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b);       \
   }
-  if (m == 16) BCG_RMUL(16) else BCG_RMUL(32)
+  if (m == 8) BCG_RMUL(8) else if (m == 16) BCG_RMUL(16) else BCG_RMUL(32)
 #undef BCG_RMUL
 }
 

@@ -8,6 +8,7 @@
 
 namespace bcg {
 
+bool mfma_rows_width(int m);    // widths whose right-multiplications (phase C, K5, K6) run on MFMA (8, 16, 32)
 bool hop_fast_width(int m);     // widths served by the LDS-staged stencil kernel (8, 16, 32)
 int phaseC_max_shifts(int m);   // shifts one phase-C launch can take (LDS budget)
 
