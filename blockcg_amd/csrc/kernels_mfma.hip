@@ -682,8 +682,19 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
                                               const double2* __restrict__ p, double c0,
                                               double2* __restrict__ partials, int ntiles, HopWalk hw, int flags) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
-  constexpr bool CARRY = GRAM;
-  constexpr int STAGES = CARRY ? 3 : 2;
+#ifndef BCG_HOP4_CARRY_PLAIN
+#define BCG_HOP4_CARRY_PLAIN 0
+#endif
+#ifndef BCG_HOP4_CARRY_B3
+#define BCG_HOP4_CARRY_B3 1
+#endif
+#ifndef BCG_HOP4_CARRY_U3
+#define BCG_HOP4_CARRY_U3 1
+#endif
+  constexpr bool CARRY = GRAM || BCG_HOP4_CARRY_PLAIN;
+  constexpr bool CARRY_B3 = CARRY && BCG_HOP4_CARRY_B3;   // -x3 neighbours from the register history
+  constexpr bool CARRY_U3 = CARRY && BCG_HOP4_CARRY_U3;   // U_3(x-3) from the previous link image
+  constexpr int STAGES = CARRY_U3 ? 3 : 2;
   (void)flags;  // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
@@ -801,7 +812,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     const bool cur_carry_u3 = carry_u3;
     have = next_tile(g);
     if (have) {  // prefetch the next tile's links; they land while this tile computes
-      carry_u3 = CARRY && g.x3 > 0 && g.site0 - S3 == cur.site0;
+      carry_u3 = CARRY_U3 && g.x3 > 0 && g.site0 - S3 == cur.site0;
       BCG_FETCH_LINKS(g, carry_u3)
     }
     // With the carry three stages, not two: the previous tile's image is READ here (U_3 carry) while a faster wave of this
@@ -840,7 +851,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     BCG_NB(3, cur.x3, L3, S3, sp3, gm3, gp3, f3, nf3, nb3)
 #undef BCG_NB
     // ---- all 24 neighbour loads first, then the arithmetic
-    const bool carry_b3 = CARRY && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
+    const bool carry_b3 = CARRY_B3 && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
     const int fsite_now = (cur.x3 + 1 < L3) ? cur.site0 + S3 : (sp3 ? -1 : cur.site0 - (L3 - 1) * S3);
     double2 f[4][3], bk[4][3];
 #pragma unroll
