@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--shifts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic VALU kernels")
+    ap.add_argument("--capacity", type=int, default=0, metavar="R",
+                    help="capacity mode: keep the operator's intermediate field as a ring of R x3 slices "
+                         "(bcg_capacity_mode); the process grid then leaves x3 undivided")
     args = ap.parse_args()
 
     import torch
@@ -106,7 +109,7 @@ def main():
         torch.cuda.set_device(device)
         backend = os.environ.get("BCG_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         dist.init_process_group(backend=backend, device_id=torch.device("cuda", device) if backend == "nccl" else None)
-        grid = grid_for(world, ndim)
+        grid = grid_for(world, ndim, keep_last=args.capacity > 0)
         coords = coords_of(rank, grid)
         comm = TorchDistComm(device)
         gdims = [l * g for l, g in zip(args.local_dims, grid)]
@@ -118,6 +121,8 @@ def main():
         ctx = bc.Context(gdims, device=device)
     if args.generic:
         ctx.force_generic(True)
+    if args.capacity:
+        ctx.capacity_mode(args.capacity)
 
     m, S = args.m, args.shifts
     shifts = sorted(SHIFTS[:S])
@@ -126,6 +131,7 @@ def main():
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
     st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0, consume_B=True)
     st.iterate(args.warmup)
+    mem_free, mem_total = torch.cuda.mem_get_info(device)  # with every field of the solve alive
 
     def barrier():
         if dist is not None:
@@ -187,6 +193,9 @@ def main():
             "hbm_roofline_frac_whole_iteration": hbm_gbps / world / HBM_PEAK_GBPS,
             "residual_after_timed_steps": residual,
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "capacity_ring_slices": args.capacity,
+            "device_bytes_planned": ctx.sbcgrq_device_bytes(m, S, consume_B=True),
+            "device_bytes_in_use": mem_total - mem_free, "device_bytes_total": mem_total,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -46,6 +46,9 @@ SIGNATURES = {
     "bcg_profile_json": (ctypes.c_char_p, [ctypes.c_void_p]),
     "bcg_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_force_generic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "bcg_capacity_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "bcg_sbcgrq_device_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_size_t)]),
     "bcg_field_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_field_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_width": (ctypes.c_int, [ctypes.c_void_p]),

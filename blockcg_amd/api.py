@@ -95,6 +95,15 @@ class Context:
     def force_generic(self, enable=True):
         self.check(self.lib.bcg_force_generic(self.h, 1 if enable else 0))
 
+    def capacity_mode(self, ring_slices):
+        """Keep dirac_op::op's intermediate field as a ring of `ring_slices` x3 slices (0: whole field)."""
+        self.check(self.lib.bcg_capacity_mode(self.h, int(ring_slices)))
+
+    def sbcgrq_device_bytes(self, m, n_shifts, consume_B=False):
+        n = ctypes.c_size_t()
+        self.check(self.lib.bcg_sbcgrq_device_bytes(self.h, m, n_shifts, 1 if consume_B else 0, ctypes.byref(n)))
+        return n.value
+
     def halo_buffers(self):
         s = ctypes.c_void_p()
         r = ctypes.c_void_p()

@@ -18,16 +18,18 @@ import torch.distributed as dist
 from . import _lib
 
 
-def grid_for(world_size, ndim):
-    """Factor world_size into a process grid, halving over the slowest directions first."""
+def grid_for(world_size, ndim, keep_last=False):
+    """Factor world_size into a process grid, halving over the slowest directions first.  keep_last leaves the last
+    direction undivided (capacity mode sweeps it slice by slice)."""
     grid = [1] * ndim
-    n, mu = world_size, ndim - 1
+    top = ndim - 2 if keep_last and ndim > 1 else ndim - 1
+    n, mu = world_size, top
     while n > 1:
         if n % 2:
             raise ValueError("world size must be a power of two")
         grid[mu] *= 2
         n //= 2
-        mu = mu - 1 if mu > 0 else ndim - 1
+        mu = mu - 1 if mu > 0 else top
     return grid
 
 

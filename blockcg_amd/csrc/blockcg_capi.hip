@@ -229,12 +229,21 @@ int halo_plan(int ndim, const int* gdims, const int* grid, const int* coords, si
 
 // Post the face messages for `site_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).  split = true uses the
 // begin half of the optional split form (the caller then issues exchange_end after the interior tiles).
-int exchange_faces(bcg_context* c, size_t site_bytes, bool split = false) {
+// x3_n > 0 (direction 3 undivided): only the slices [x3_lo, x3_lo + x3_n), a contiguous sub-range of every face.
+int exchange_faces(bcg_context* c, size_t site_bytes, bool split = false, int x3_lo = 0, int x3_n = 0) {
   if (!c->have_comm || !c->comm.halo_exchange) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
   int peer_s[8], peer_r[8];
   size_t off_s[8], off_r[8], nb[8];
   const int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
   if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
+  if (x3_n > 0) {
+    for (int k = 0; k < n; ++k) {
+      const size_t slice = nb[k] / c->lat.L[3];
+      off_s[k] += slice * x3_lo;
+      off_r[k] += slice * x3_lo;
+      nb[k] = slice * x3_n;
+    }
+  }
   auto fn = split ? c->comm.halo_exchange_begin : c->comm.halo_exchange;
   if (fn(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0) BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
   return BCG_OK;
@@ -258,6 +267,21 @@ int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
   BCG_TRY(check_launch(c, "pack_faces"));
   ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
   return exchange_faces(c, site_bytes, split);
+}
+
+// Faces of the x3 slices [x3_lo, x3_lo + x3_n) only; `d` is a whole field (ring = 0) or a ring of slices (capacity mode).
+// The other slices' ranges of the ghost buffer keep what they held.
+int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring) {
+  if (!c->distributed) return BCG_OK;
+  const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
+  BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
+  {
+    ProfScope ps(c, "pack_faces");
+    bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3_lo, x3_n, ring);
+  }
+  BCG_TRY(check_launch(c, "pack_faces"));
+  ProfScope ps(c, "halo_exchange");
+  return exchange_faces(c, site_bytes, false, x3_lo, x3_n);
 }
 
 int halo_gauge(bcg_context* c, bcg_gauge* g) {
@@ -412,9 +436,72 @@ int get_tmp(bcg_context* c, int m, bcg_field** out) {
   return BCG_OK;
 }
 
+// Capacity mode (bcg_capacity_mode): the same T = (mass^2 + sigma0) P - D(D(P)), with tmp = D P held as a ring of R x3
+// slices instead of a whole field.  Direction 3 is undivided, so a slice of T needs the slices x3-1, x3, x3+1 of tmp and
+// nothing else of it: the first stencil runs C = R - 2 slices ahead of the second.
+//   tmp[L3-1]; then per chunk [lo, hi) of C slices: tmp[.. hi] (slice L3 = slice 0 again), faces of tmp[lo, hi) to the
+//   neighbours, T[lo, hi).  Writing slice s of tmp replaces slice s - R, which no later chunk reads.
+// Slices L3-1 and 0 of tmp are computed twice (2/L3 more work in the first stencil).  The ghost buffer is shared: the faces of
+// tmp[lo, hi) land on the range that held the faces of P[lo, hi), which the first stencil no longer reads -- except
+// slice 0 at the very end, whose P faces are exchanged again.  The exchanges are not overlapped with arithmetic in this mode.
+bool capacity_path(const bcg_context* c, int m) {
+  return c->tmp_ring > 0 && fast_hop(c, m) && bcg::hop_can_split_tiles(m, c->lat);
+}
+int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
+                       int* gram_blocks) {
+  const int m = P->m, R = c->tmp_ring, C = R - 2, L3 = c->lat.L[3];
+  BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+  double2*& ring = c->tmp_ring_buf[m];
+  if (!ring) HIP_TRY(c, hipMalloc(&ring, static_cast<size_t>(R) * c->lat.stride[3] * 3 * m * sizeof(double2)));
+  if (gram_blocks) *gram_blocks = 0;
+  const bool gram = gram_blocks && m == 16;
+  BCG_TRY(ensure_scratch(c));
+  // block partials of all chunks side by side
+  const int chunks = (L3 + C - 1) / C;
+  const size_t cap = c->partials_bytes / (static_cast<size_t>(m) * m * sizeof(double2));
+  bcg::HopTuning tune = c->hop_tune;
+  if (gram && static_cast<size_t>(tune.blocks) * chunks > cap) tune.blocks = static_cast<int>(cap / chunks) & ~7;
+  if (tune.blocks < 8) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: too many chunks for the Gram partials buffer");
+  BCG_TRY(halo_field(c, P));
+  auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
+    ProfScope ps(c, "hop_ring");
+    const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
+                                        0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});
+    if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
+    return check_launch(c, "hop_ring");
+  };
+  const double c0 = mass * mass + sigma0;
+  int total = 0;
+  BCG_TRY(first(L3 - 1, 1));
+  int next = 0;  // first slice of tmp not yet computed in order (L3 stands for slice 0 again)
+  for (int lo = 0; lo < L3; lo += C) {
+    const int hi = lo + C < L3 ? lo + C : L3;
+    const int last = hi < L3 ? hi : L3 - 1;
+    if (next <= last) BCG_TRY(first(next, last - next + 1));
+    if (hi == L3) {
+      BCG_TRY(halo_window(c, m, P->d, 0, 1, 0));  // its P faces were replaced by tmp faces of the first chunk
+      BCG_TRY(first(0, 1));
+    }
+    next = hi + 1;
+    BCG_TRY(halo_window(c, m, ring, lo, hi - lo, R));
+    {
+      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring");
+      const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
+                                          c0, c->partials + static_cast<size_t>(total) * m * m, gram, kFastBlocks, tune, 0,
+                                          bcg::HopWindow{lo, hi - lo, R});
+      if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
+      total += nb;
+    }
+    BCG_TRY(check_launch(c, "hop_shifted_ring"));
+  }
+  if (gram) *gram_blocks = total;
+  return BCG_OK;
+}
+
 // T = (mass^2 + sigma0) P - D(D(P))   [op + add(P, sigma0), inc/block_solvers.hpp:134-136]
 int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
                   int* gram_blocks = nullptr) {
+  if (capacity_path(c, P->m)) return apply_shifted_ring(c, g, mass, sigma0, T, P, gram_blocks);
   bcg_field* tmp;
   BCG_TRY(get_tmp(c, P->m, &tmp));
   BCG_TRY(hop(c, g, tmp, P, bcg::HOP_PLAIN, nullptr, 0.0));
@@ -593,6 +680,8 @@ int bcg_context_destroy(bcg_context* c) {
     (void)hipFree(kv.second->d);
     delete kv.second;
   }
+  for (auto& kv : c->tmp_ring_buf)
+    if (kv.second) (void)hipFree(kv.second);
   if (c->halo_send) (void)hipFree(c->halo_send);
   if (c->halo_recv) (void)hipFree(c->halo_recv);
   if (c->partials) (void)hipFree(c->partials);
@@ -691,6 +780,43 @@ const char* bcg_profile_json(bcg_context* c) {
 int bcg_force_generic(bcg_context* c, int enable) {
   if (!c) return BCG_ERR_INVALID;
   c->force_generic = enable != 0;
+  return BCG_OK;
+}
+
+int bcg_capacity_mode(bcg_context* c, int ring_slices) {
+  if (!c) return BCG_ERR_INVALID;
+  if (ring_slices != 0) {
+    if (c->lat.ndim != 4 || c->lat.split[3])
+      BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode needs a 4-D lattice whose last direction is not divided over ranks");
+    if (ring_slices < 3 || ring_slices > c->lat.L[3] || c->lat.L[3] % ring_slices != 0)
+      BCG_FAIL(c, BCG_ERR_INVALID, "capacity mode: ring_slices must be >= 3 and divide the local extent of direction 3");
+  }
+  if (ring_slices != c->tmp_ring) {  // drop scratch of the other mode
+    BCG_TRY(stream_sync(c));
+    for (auto& kv : c->tmp_ring_buf)
+      if (kv.second) (void)hipFree(kv.second);
+    c->tmp_ring_buf.clear();
+    if (ring_slices != 0) {
+      for (auto& kv : c->tmp_field) {
+        (void)hipFree(kv.second->d);
+        delete kv.second;
+      }
+      c->tmp_field.clear();
+    }
+  }
+  c->tmp_ring = ring_slices;
+  return BCG_OK;
+}
+
+int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consume_B, size_t* bytes_out) {
+  if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
+  const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
+  size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
+  total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
+  total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
+  total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
+  total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
+  *bytes_out = total;
   return BCG_OK;
 }
 

@@ -39,7 +39,10 @@ void launch_fill_gauge(hipStream_t s, const LatticeDev& lat, const int* gdims, d
 // ---- halo -------------------------------------------------------------------------------------
 // Gather the low (x_mu = 0) and high (x_mu = L-1) faces of every split direction into `send`:
 // per split mu, [low face][high face], each face_sites[mu] * 3m complex.
-void launch_pack_faces(hipStream_t s, int m, const LatticeDev& lat, const double2* f, double2* send);
+// x3_n > 0 restricts the faces to the slices [x3_lo, x3_lo + x3_n) of an undivided direction 3 (a contiguous range of
+// every face); ring > 0: f is a ring of `ring` x3-slices, slice x3 in slot x3 % ring (capacity mode).
+void launch_pack_faces(hipStream_t s, int m, const LatticeDev& lat, const double2* f, double2* send, int x3_lo = 0,
+                       int x3_n = 0, int ring = 0);
 // Same for the gauge links U_mu of direction mu only (9 complex per site).
 void launch_pack_gauge_faces(hipStream_t s, const LatticeDev& lat, const double2* U, double2* send);
 

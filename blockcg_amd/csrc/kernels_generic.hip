@@ -169,7 +169,8 @@ __global__ void k_fill_gauge(LatticeDev lat, GDims g, double2* __restrict__ U, u
 }
 
 // one thread per complex element of one face; grid.y = 2*k + side for the k-th split direction
-__global__ void k_pack_faces(int m, LatticeDev lat, const double2* __restrict__ f, double2* __restrict__ send) {
+__global__ void k_pack_faces(int m, LatticeDev lat, const double2* __restrict__ f, double2* __restrict__ send, int x3_lo,
+                             int x3_n, int ring) {
   int mu = -1, k = blockIdx.y >> 1;
   const int side = blockIdx.y & 1;
   int64_t base_sites = 0;
@@ -181,14 +182,22 @@ __global__ void k_pack_faces(int m, LatticeDev lat, const double2* __restrict__ 
   }
   if (mu < 0) return;
   const int row = 3 * m;
-  const int64_t n = lat.face_sites[mu] * row;
-  double2* dst = send + (base_sites + side * lat.face_sites[mu]) * row;
+  // x3 window (direction 3 undivided, so mu < 3 and x3 is the slowest face coordinate): a contiguous range of the face
+  const int64_t slice = x3_n > 0 ? lat.face_sites[mu] / lat.L[3] : 0;
+  const int64_t first = x3_n > 0 ? x3_lo * slice : 0;
+  const int64_t n = (x3_n > 0 ? x3_n * slice : lat.face_sites[mu]) * row;
+  double2* dst = send + (base_sites + side * lat.face_sites[mu] + first) * row;
   const int xmu = side ? lat.L[mu] - 1 : 0;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const int64_t fs = i / row;
     const int e = static_cast<int>(i - fs * row);
-    dst[i] = f[face_to_site(lat, fs, mu, xmu) * row + e];
+    int64_t site = face_to_site(lat, first + fs, mu, xmu);
+    if (ring > 0) {  // slice x3 of the field lives in slot x3 % ring
+      const int64_t x3 = site / lat.stride[3];
+      site += (x3 % ring - x3) * lat.stride[3];
+    }
+    dst[i] = f[site * row + e];
   }
 }
 // gauge: only U_mu of the split direction mu itself, 9 complex per site
@@ -521,11 +530,14 @@ static int64_t max_face(const LatticeDev& lat) {
     if (lat.split[mu] && lat.face_sites[mu] > f) f = lat.face_sites[mu];
   return f;
 }
-void launch_pack_faces(hipStream_t s, int m, const LatticeDev& lat, const double2* f, double2* send) {
+void launch_pack_faces(hipStream_t s, int m, const LatticeDev& lat, const double2* f, double2* send, int x3_lo, int x3_n,
+                       int ring) {
   const int ns = n_split(lat);
   if (ns == 0) return;
-  hipLaunchKernelGGL(k_pack_faces, dim3(grid_for(max_face(lat) * 3 * m, 256, 4096), 2 * ns), dim3(256), 0, s, m, lat,
-                     f, send);
+  int64_t work = max_face(lat) * 3 * m;
+  if (x3_n > 0) work = work / lat.L[3] * x3_n;
+  hipLaunchKernelGGL(k_pack_faces, dim3(grid_for(work, 256, 4096), 2 * ns), dim3(256), 0, s, m, lat, f, send, x3_lo, x3_n,
+                     ring);
 }
 void launch_pack_gauge_faces(hipStream_t s, const LatticeDev& lat, const double2* U, double2* send) {
   const int ns = n_split(lat);

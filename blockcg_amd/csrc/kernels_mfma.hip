@@ -629,12 +629,12 @@ __device__ __forceinline__ void digits_add(Digits& a, const Digits& s, int r0, i
 #undef BCG_ADD_DIGIT
 
 template <int SPB>
-__device__ __forceinline__ TileGeom geom_of(const Digits& d, int r0, int p1, int p2, int L0, int L1, int L2) {
+__device__ __forceinline__ TileGeom geom_of(const Digits& d, int r0, int p1, int p2, int L0, int L1, int L2, int x3_lo) {
   TileGeom g;
   g.x0b = (d.d4 * r0 + d.d0) * SPB;
   g.x1 = d.d5 * p1 + d.d1;
   g.x2 = d.d6 * p2 + d.d2;
-  g.x3 = d.d3;
+  g.x3 = x3_lo + d.d3;
   g.site0 = g.x0b + L0 * (g.x1 + L1 * (g.x2 + L2 * g.x3));
   return g;
 }
@@ -675,13 +675,16 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
 // of 2 waves per SIMD in __launch_bounds__ costs 1.5 ms on both, so: CARRY = GRAM, plain __launch_bounds__(256).
 // CLS selects the tiles a launch processes: 0 all, 1 interior only (no site of the tile reads a ghost), 2 boundary only.
 // Interior and boundary launches bracket the halo exchange so that it overlaps the interior arithmetic.
-template <int M, int MODE, bool GRAM, bool NT, int CLS>
+template <int M, int MODE, bool GRAM, bool NT, int CLS, bool RING>
 __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                               const double2* __restrict__ ghost, double2* __restrict__ out,
                                               const double2* __restrict__ p, double c0,
-                                              double2* __restrict__ partials, int ntiles, HopWalk hw, int flags) {
+                                              double2* __restrict__ partials, int ntiles, HopWalk hw, HopWindow win) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  // capacity mode (HopWindow::ring): the intermediate field is a ring of x3 slices, written by HOP_PLAIN, read by HOP_SHIFTED
+  constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
+  constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
 #ifndef BCG_HOP4_CARRY_PLAIN
 #define BCG_HOP4_CARRY_PLAIN 0
 #endif
@@ -695,7 +698,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   constexpr bool CARRY_B3 = CARRY && BCG_HOP4_CARRY_B3;   // -x3 neighbours from the register history
   constexpr bool CARRY_U3 = CARRY && BCG_HOP4_CARRY_U3;   // U_3(x-3) from the previous link image
   constexpr int STAGES = CARRY_U3 ? 3 : 2;
-  (void)flags;  // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
+  // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
   constexpr int SPW = 64 / M;
   constexpr int SPB = 4 * SPW;
   constexpr int NW = 4;
@@ -727,7 +730,8 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   if (GRAM) gram_zero(G);
 
   // ---- tile sequence of this block
-  const int r0 = hw.p0 / SPB, r1 = hw.p1, r2 = hw.p2, r3 = L3, r4 = L0 / hw.p0, r5 = L1 / hw.p1;
+  const int r0 = hw.p0 / SPB, r1 = hw.p1, r2 = hw.p2, r3 = win.x3_n, r4 = L0 / hw.p0, r5 = L1 / hw.p1;
+  const int x3_lo = win.x3_lo;
   unsigned start = blockIdx.x, step = gridDim.x, left;
   if (hw.xcd_split) {
     const unsigned cnt = ntiles >> 3, cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -771,12 +775,12 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     while (left > 0) {
       digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
       --left;
-      t = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+      t = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2, x3_lo);
       if (wanted(t)) return true;
     }
     return false;
   };
-  TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2);
+  TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2, x3_lo);
   bool have = left > 0;
   if (have) {
     --left;  // `left` now counts the positions after the current one
@@ -830,25 +834,35 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     const int f1 = cur.x0b + L0 * (cur.x2 + L2 * cur.x3);          // directions 1..3: index of the tile's first site
     const int f2 = cur.x0b + L0 * (cur.x1 + L1 * cur.x3);
     const int f3 = cur.x0b + L0 * (cur.x1 + L1 * cur.x2);
+    // ring addressing: slot of this tile's slice; direction 3 is undivided and ring | L3, so the neighbour slices are
+    // the neighbour slots (with wrap-around)
+    const int slot = RING ? cur.x3 % win.ring : 0;
+    const int64_t base = me - static_cast<int64_t>(cur.x3) * S3;   // site within the slice
+    const int64_t mi = RING_IN ? base + static_cast<int64_t>(slot) * S3 : me;  // this site in the input field
     const double2 *nf0, *nb0, *nf1, *nb1, *nf2, *nb2, *nf3, *nb3;
-    if (x0 + 1 < L0) nf0 = in + (me + 1) * 3 * M;
-    else if (!sp0) nf0 = in + (me + 1 - L0) * 3 * M;
+    if (x0 + 1 < L0) nf0 = in + (mi + 1) * 3 * M;
+    else if (!sp0) nf0 = in + (mi + 1 - L0) * 3 * M;
     else nf0 = ghost + (gp0 + f0) * 3 * M;
-    if (x0 > 0) nb0 = in + (me - 1) * 3 * M;
-    else if (!sp0) nb0 = in + (me - 1 + L0) * 3 * M;
+    if (x0 > 0) nb0 = in + (mi - 1) * 3 * M;
+    else if (!sp0) nb0 = in + (mi - 1 + L0) * 3 * M;
     else nb0 = ghost + (gm0 + f0) * 3 * M;
 #define BCG_NB(MU, XM, LM, SM, SPM, GM, GP, FI, NF_, NB_)                                   \
   {                                                                                         \
-    if ((XM) + 1 < (LM)) NF_ = in + (me + (SM)) * 3 * M;                                    \
-    else if (!(SPM)) NF_ = in + (me - static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
+    if ((XM) + 1 < (LM)) NF_ = in + (mi + (SM)) * 3 * M;                                    \
+    else if (!(SPM)) NF_ = in + (mi - static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
     else NF_ = ghost + ((GP) + (FI) + sl) * 3 * M;                                          \
-    if ((XM) > 0) NB_ = in + (me - (SM)) * 3 * M;                                           \
-    else if (!(SPM)) NB_ = in + (me + static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
+    if ((XM) > 0) NB_ = in + (mi - (SM)) * 3 * M;                                           \
+    else if (!(SPM)) NB_ = in + (mi + static_cast<int64_t>((LM) - 1) * (SM)) * 3 * M;       \
     else NB_ = ghost + ((GM) + (FI) + sl) * 3 * M;                                          \
   }
     BCG_NB(1, cur.x1, L1, S1, sp1, gm1, gp1, f1, nf1, nb1)
     BCG_NB(2, cur.x2, L2, S2, sp2, gm2, gp2, f2, nf2, nb2)
-    BCG_NB(3, cur.x3, L3, S3, sp3, gm3, gp3, f3, nf3, nb3)
+    if (RING_IN) {
+      nf3 = in + (base + static_cast<int64_t>(slot + 1 == win.ring ? 0 : slot + 1) * S3) * 3 * M;
+      nb3 = in + (base + static_cast<int64_t>(slot == 0 ? win.ring - 1 : slot - 1) * S3) * 3 * M;
+    } else {
+      BCG_NB(3, cur.x3, L3, S3, sp3, gm3, gp3, f3, nf3, nb3)
+    }
 #undef BCG_NB
     // ---- all 24 neighbour loads first, then the arithmetic
     const bool carry_b3 = CARRY_B3 && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
@@ -880,6 +894,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     (void)site_m1;
     double2 pv[3];
     const int64_t o0 = me * 3 * M + j;
+    const int64_t oo = RING_OUT ? (base + static_cast<int64_t>(slot) * S3) * 3 * M + j : o0;
     if (MODE == HOP_SHIFTED) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) pv[r] = NT ? ld_nt(p + o0 + r * M) : p[o0 + r * M];
@@ -917,8 +932,8 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     for (int r = 0; r < 3; ++r) {
       if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
       else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-      if (NT) st_nt(out + o0 + r * M, tv[r]);  // streamed once: keep it from displacing the patch slices in L2
-      else out[o0 + r * M] = tv[r];
+      if (NT) st_nt(out + oo + r * M, tv[r]);  // streamed once: keep it from displacing the patch slices in L2
+      else out[oo + r * M] = tv[r];
     }
     if (GRAM) {
 #pragma unroll
@@ -1026,9 +1041,13 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
 template <int M>
 static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
                        const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
-                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int flags, int cls) {
+                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int cls, HopWindow win) {
   constexpr int SPB = 4 * (64 / M);
-  const int ntiles = static_cast<int>(lat.V / SPB);
+  if (win.x3_n <= 0) win = HopWindow{0, lat.L[3], win.ring};
+  if (win.x3_lo < 0 || win.x3_lo + win.x3_n > lat.L[3]) return -1;
+  // ring addressing: whole tiles only (no interior/boundary split), direction 3 undivided, ring | L3
+  if (win.ring > 0 && (cls != 0 || lat.split[3] || win.ring < 3 || lat.L[3] % win.ring != 0)) return -1;
+  const int ntiles = static_cast<int>(lat.V / lat.L[3] * win.x3_n / SPB);
   const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
                    lat.L[2] % p2 == 0 && ntiles % 8 == 0 && max_blocks % 8 == 0 && ntiles / 8 >= max_blocks / 8;
   HopWalk hw{lat.L[0], lat.L[1], lat.L[2], 0};  // lexicographic = one patch
@@ -1038,18 +1057,19 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
-  (void)flags;  // the streaming (non-temporal) form is the only one instantiated
-#define BCG_LAUNCH4(MM, MD, GR, CL)                                                                                      \
+  // the streaming (non-temporal) form is the only one instantiated
+#define BCG_LAUNCH4(MM, MD, GR, CL, RG)                                                                                   \
   do {                                                                                                                   \
-    allow_lds(k_hop4<MM, MD, GR, true, CL>, lds);                                                                        \
-    hipLaunchKernelGGL((k_hop4<MM, MD, GR, true, CL>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
-                       c0, partials, ntiles, hw, flags);                                                                 \
+    allow_lds(k_hop4<MM, MD, GR, true, CL, RG>, lds);                                                                    \
+    hipLaunchKernelGGL((k_hop4<MM, MD, GR, true, CL, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
+                       p, c0, partials, ntiles, hw, win);                                                                \
   } while (0)
-#define BCG_LAUNCH4_CLS(MM, MD, GR)                 \
-  do {                                              \
-    if (cls == 1) BCG_LAUNCH4(MM, MD, GR, 1);       \
-    else if (cls == 2) BCG_LAUNCH4(MM, MD, GR, 2);  \
-    else BCG_LAUNCH4(MM, MD, GR, 0);                \
+#define BCG_LAUNCH4_CLS(MM, MD, GR)                          \
+  do {                                                       \
+    if (win.ring > 0) BCG_LAUNCH4(MM, MD, GR, 0, true);      \
+    else if (cls == 1) BCG_LAUNCH4(MM, MD, GR, 1, false);    \
+    else if (cls == 2) BCG_LAUNCH4(MM, MD, GR, 2, false);    \
+    else BCG_LAUNCH4(MM, MD, GR, 0, false);                  \
   } while (0)
   if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4_CLS(16, HOP_SHIFTED, true);
   else if (mode == HOP_PLAIN) BCG_LAUNCH4_CLS(M, HOP_PLAIN, false);
@@ -1061,16 +1081,19 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class) {
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class,
+                    const HopWindow& win) {
   const int spb = 4 * (64 / m);
   // specialised 4-D kernel: tile = spb consecutive x0 sites of one row, 32-bit site arithmetic
   if (hop_can_split_tiles(m, lat)) {
-    const int walk = tune.patch_walk ? 3 : 0, flags = tune.nontemporal ? 1 : 0;
+    const int walk = tune.patch_walk ? 3 : 0;
     const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
-    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
-    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
-    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, tune.patch[0], tune.patch[1], tune.patch[2], flags, tile_class);
+    const int* pt = tune.patch;
+    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
+    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
+    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
   }
+  if (win.x3_n > 0 || win.ring > 0) return -1;  // x3 windows and ring addressing exist in the specialised kernel only
   if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles
   const int64_t ntiles = (lat.V + spb - 1) / spb;
   const int grid = grid_tiles(ntiles, 1, max_blocks);

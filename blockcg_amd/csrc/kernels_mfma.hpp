@@ -33,10 +33,20 @@ struct HopTuning {
                                  // so CUs are not vacated for the transport; its kernels co-reside where registers allow
 };
 
+// Restriction of one stencil launch to the x3 slices [x3_lo, x3_lo + x3_n) and, with ring > 0, the capacity-mode
+// addressing of the intermediate field of dirac_op::op (inc/dirac_op.hpp:39, `tmp`): slice x3 of that field lives in slot
+// x3 % ring of a buffer of `ring` slices.  HOP_PLAIN writes its output there, HOP_SHIFTED reads its input from
+// there (U, p, the HOP_SHIFTED output and the ghost faces keep the whole-lattice addressing).  Specialised 4-D kernel only.
+struct HopWindow {
+  int x3_lo = 0, x3_n = 0;  // x3_n = 0: all slices
+  int ring = 0;
+};
+
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
-                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class);
+                    double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class,
+                    const HopWindow& win = HopWindow());
 // true when launch_hop_fast can process interior (tile_class 1) and boundary (2) tiles in separate launches
 bool hop_can_split_tiles(int m, const LatticeDev& lat);
 

@@ -107,6 +107,18 @@ const char* bcg_profile_json(bcg_context* ctx);
 int bcg_profile_reset(bcg_context* ctx);
 /* Force the generic (any-m, VALU) kernels even where an MFMA fast path exists; for parity tests. */
 int bcg_force_generic(bcg_context* ctx, int enable);
+/* Capacity mode.  dirac_op::op (inc/dirac_op.hpp:36-43) holds a whole field `tmp` = D P between its two stencil
+ * applications.  With ring_slices = R > 0 the library keeps only R slices of `tmp` (slices of the last direction x3) and
+ * runs the second application R-2 slices behind the first, so the solver's working set shrinks by (1 - R/L3) of a
+ * field: what lets 128^4 sites x 16 right-hand sides x 4 shifts fit 8 x 288 GiB.  Results equal the default mode's up to
+ * the summation order of the fused Gram product.  Requires a 4-D lattice whose direction 3 is not divided over ranks,
+ * R >= 3 and R | L3 (else BCG_ERR_UNSUPPORTED / BCG_ERR_INVALID); applies to the widths of the specialised stencil
+ * (8, 16, 32 with L0 a multiple of the tile length), other widths keep the whole `tmp`.  Halo exchanges are issued per
+ * chunk of R-2 slices and are not overlapped with arithmetic.  0 switches back. */
+int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
+/* Device memory one SBCGrQ solve of width m with n_shifts shifts occupies on this rank in the current mode: X_s, P_s,
+ * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch.  Host arithmetic only. */
+int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
 
 /* ---- fields: block_fermion_field<N_rhs> (inc/fields.hpp:25-147) --------------------------- */
 int bcg_field_create(bcg_context* ctx, int m, bcg_field** f);          /* explicit ctor :35 (contents undefined) */

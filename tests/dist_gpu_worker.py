@@ -31,6 +31,7 @@ def main():
     ctx = bc.Context(gdims, device=0, grid=grid, coords=coords, stream=comm.stream_ptr)
     comm.attach(ctx)
     ctx.force_generic(generic)
+    ctx.capacity_mode(int(os.environ.get("BCG_TEST_RING", "0")))
     mass, shifts, iters = 0.1, [0.0, 1e-3, 1e-1], 4
     D = bc.dirac_op(ctx, mass, seed=3)
     B = bc.block_fermion_field(ctx, m).setRandom(seed=4)

@@ -24,20 +24,38 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dims,grid,m,generic", CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
-def test_domain_decomposed_solve(dims, grid, m, generic):
+def _run_ranks(dims, grid, m, generic, ring=0):
     world = 1
     for g in grid:
         world *= g
     env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)),
-               BCG_TEST_M=str(m), BCG_TEST_GENERIC="1" if generic else "0", OMP_NUM_THREADS="1",
+               BCG_TEST_M=str(m), BCG_TEST_GENERIC="1" if generic else "0", BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1",
                BCG_HOP_BLOCKS="8", BCG_HOP_PATCH="16,2,2")
-    port = 29700 + (hash((tuple(dims), tuple(grid), m)) % 200)
+    port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU_OK" in out.stdout
+
+
+@pytest.mark.parametrize("dims,grid,m,generic", CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_domain_decomposed_solve(dims, grid, m, generic):
+    _run_ranks(dims, grid, m, generic)
+
+
+RING_CASES = [
+    # dims,            grid,          m,  ring slices (x3 undivided; faces of the ring exchanged per chunk of ring-2 slices)
+    ([32, 4, 4, 8], [2, 1, 1, 1], 16, 4),    # x0 split
+    ([16, 8, 8, 6], [1, 2, 2, 1], 16, 3),    # 4 ranks, x1 and x2 split, one-slice chunks
+    ([64, 4, 4, 8], [2, 1, 2, 1], 8, 8),     # m = 8, ring = L3
+    ([16, 4, 4, 12], [2, 1, 1, 1], 32, 4),   # m = 32
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,ring", RING_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_domain_decomposed_solve_capacity_mode(dims, grid, m, ring):
+    _run_ranks(dims, grid, m, False, ring)
 
 
 def test_rccl_on_library_memory_views():

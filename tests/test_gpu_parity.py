@@ -413,3 +413,62 @@ def test_degenerate_lattices(bc, orc, dims, m):
     assert not X[0].download().any()                         # X is zeroed even when no iteration runs (:111-113)
     it = bc.SBCGrQ(X, B, D, [0.25], 1e-10, max_iterations=200)
     assert it <= 200 and bc.true_residuals(X, B, D, [0.25]).max() < 2e-10
+
+
+@pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 3), (16, [32, 4, 4, 12], 4), (16, [16, 8, 4, 6], 6),
+                                         (16, [64, 4, 2, 8], 4), (8, [32, 4, 4, 8], 4), (32, [16, 4, 4, 6], 3)])
+@pytest.mark.parametrize("walk,blocks", [("3", "8"), ("0", "768")])
+def test_capacity_mode_matches_default_and_oracle(bc, orc, m, dims, ring, walk, blocks, monkeypatch):
+    """bcg_capacity_mode: dirac_op::op's intermediate field kept as a ring of x3 slices (the second stencil runs ring-2
+    slices behind the first, slices L3-1 and 0 computed twice).  Operator, fused Gram product and a fixed number of
+    SBCGrQ iterations against the whole-field mode and the oracle."""
+    monkeypatch.setenv("BCG_HOP_WALK", walk)
+    monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 61)
+    Bh = orc.fill_field(m, V, 62)
+    shifts, iters = [0.0, 0.02, 0.3], 5
+    res = {}
+    for mode in (0, ring):
+        ctx = bc.Context(dims)
+        ctx.capacity_mode(mode)
+        D = bc.dirac_op(ctx, 0.2, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        out = bc.block_fermion_field(ctx, m)
+        D.op(out, B)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        info = bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters, return_info=True)
+        res[mode] = (out.download(), [x.download() for x in X], info["trace"], ctx.sbcgrq_device_bytes(m, len(shifts)))
+    assert np.array_equal(res[0][0], res[ring][0])  # the operator alone: same arithmetic per site, bit for bit
+    assert rel_err(res[ring][0], orc.dirac_apply(U, dims, 0.2, Bh)) < TOL_KERNEL
+    o = orc.sbcgrq(U, dims, 0.2, Bh, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters)
+    for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+        assert rel_err(res[ring][2][key], res[0][2][key]) < 1e-11, key
+        assert rel_err(res[ring][2][key], o["trace"][key]) < TOL_COEFF, key
+    for s in range(len(shifts)):
+        assert rel_err(res[ring][1][s], res[0][1][s]) < 1e-11
+        assert rel_err(res[ring][1][s], o["X"][s]) < 1e-10
+    field = V * 3 * m * 16
+    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring  # what the mode is for
+
+
+def test_capacity_mode_arguments(bc):
+    ctx = bc.Context([16, 4, 4, 12])
+    for bad in (1, 2, 5, 24):
+        with pytest.raises(bc.BlockCGError) as e:
+            ctx.capacity_mode(bad)
+        assert e.value.code == 1
+    ctx.capacity_mode(12)
+    ctx.capacity_mode(0)
+    with pytest.raises(bc.BlockCGError) as e:
+        bc.Context([16, 4, 12]).capacity_mode(3)
+    assert e.value.code == 2
+    # widths outside the specialised stencil keep the whole intermediate field and still solve
+    ctx = bc.Context([8, 4, 4, 6])
+    ctx.capacity_mode(3)
+    D = bc.dirac_op(ctx, 0.5, seed=1)
+    B = bc.block_fermion_field(ctx, 4).setRandom(seed=2)
+    X = [bc.block_fermion_field(ctx, 4)]
+    bc.SBCGrQ(X, B, D, [0.1], 1e-10, max_iterations=300)
+    assert bc.true_residuals(X, B, D, [0.1]).max() < 2e-10
