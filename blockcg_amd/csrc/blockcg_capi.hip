@@ -124,8 +124,8 @@ constexpr int kMatSlots = 96;
 
 int ensure_scratch(bcg_context* c) {
   if (!c->partials) {
+    HIP_TRY(c, hipMalloc(&c->partials, static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2)));
     c->partials_bytes = static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2);
-    HIP_TRY(c, hipMalloc(&c->partials, c->partials_bytes));
   }
   if (!c->dev_mats) {
     c->mat_slot_bytes = kMatSlotBytes;
@@ -456,12 +456,18 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   if (gram_blocks) *gram_blocks = 0;
   const bool gram = gram_blocks && m == 16;
   BCG_TRY(ensure_scratch(c));
-  // block partials of all chunks side by side
+  // block partials of all chunks side by side (the stencil grid stays the tuned one: a smaller grid loses the x3 walk)
   const int chunks = (L3 + C - 1) / C;
-  const size_t cap = c->partials_bytes / (static_cast<size_t>(m) * m * sizeof(double2));
-  bcg::HopTuning tune = c->hop_tune;
-  if (gram && static_cast<size_t>(tune.blocks) * chunks > cap) tune.blocks = static_cast<int>(cap / chunks) & ~7;
-  if (tune.blocks < 8) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: too many chunks for the Gram partials buffer");
+  const bcg::HopTuning& tune = c->hop_tune;
+  const size_t need = static_cast<size_t>(tune.blocks > 0 ? tune.blocks : kFastBlocks) * chunks * m * m * sizeof(double2);
+  if (gram && need > c->partials_bytes) {
+    BCG_TRY(stream_sync(c));
+    (void)hipFree(c->partials);
+    c->partials = nullptr;
+    c->partials_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->partials, need));
+    c->partials_bytes = need;
+  }
   BCG_TRY(halo_field(c, P));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
     ProfScope ps(c, "hop_ring");

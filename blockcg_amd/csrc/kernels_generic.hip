@@ -441,12 +441,12 @@ __global__ void __launch_bounds__(256) k_gram_generic(int64_t rows, const double
   }
 }
 
-// out[p] = sum over blocks in index order: pairwise-free, fixed order => deterministic.
-// 8 lanes cooperate on one value (strided partial sums, then a fixed-order combine).
+// out[p] = sum over blocks in a fixed order (deterministic): W lanes cooperate on one value (strided partial sums,
+// then a fixed-order combine).  W = 8, or 64 when there are thousands of blocks (capacity mode's chunked stencil).
+template <int W>
 __global__ void __launch_bounds__(256) k_reduce_partials(int n_values, int n_blocks,
                                                          const double2* __restrict__ partials,
                                                          double2* __restrict__ out) {
-  constexpr int W = 8;
   __shared__ double2 sh[256];
   const int v = blockIdx.x * (256 / W) + threadIdx.x / W;
   const int w = threadIdx.x % W;
@@ -591,7 +591,10 @@ int launch_gram_generic(hipStream_t s, int m, int64_t rows, const double2* a, co
 }
 
 void launch_reduce_partials(hipStream_t s, int n_values, int n_blocks, const double2* partials, double2* out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3((n_values + 31) / 32), dim3(256), 0, s, n_values, n_blocks, partials, out);
+  if (n_blocks > 2048)
+    hipLaunchKernelGGL(k_reduce_partials<64>, dim3((n_values + 3) / 4), dim3(256), 0, s, n_values, n_blocks, partials, out);
+  else
+    hipLaunchKernelGGL(k_reduce_partials<8>, dim3((n_values + 31) / 32), dim3(256), 0, s, n_values, n_blocks, partials, out);
 }
 
 }  // namespace bcg
