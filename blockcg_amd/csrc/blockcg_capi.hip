@@ -133,6 +133,11 @@ int ensure_scratch(bcg_context* c) {
     HIP_TRY(c, hipMalloc(&c->dev_mats, kMatSlotBytes * kMatSlots));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_mats), kMatSlotBytes * kMatSlots, hipHostMallocDefault));
   }
+  if (!c->hop_tune.sync.counters) {  // pacing counters of the specialised stencil (HopSync)
+    constexpr int kSyncStride = 8192;
+    HIP_TRY(c, hipMalloc(&c->hop_tune.sync.counters, sizeof(unsigned) * 8 * kSyncStride));
+    c->hop_tune.sync.stride = kSyncStride;
+  }
   if (!c->dev_gram) {
     HIP_TRY(c, hipMalloc(&c->dev_gram, kMatSlotBytes));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_gram), kMatSlotBytes, hipHostMallocDefault));
@@ -306,6 +311,15 @@ inline bool fast_rmul(const bcg_context* c, int m) { return !c->force_generic &&
 inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
 constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
 
+// Profiling only: count the launches of each form of the stencil kernel ("stencil_form_k_hop4c" ...), so that tests
+// and tuning runs can tell which one a lattice shape gets.
+void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win) {
+  if (!c->profiling) return;
+  static const char* names[] = {"stencil_form_general", "stencil_form_k_hop4", "stencil_form_k_hop4c"};
+  const int form = bcg::hop_kernel_form(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win);
+  if (form >= 0 && form <= 2) c->prof[names[form]].count += 1;
+}
+
 // out = D in  (HOP_PLAIN)  or  out = c0*p - D in  (HOP_SHIFTED).  With gram_blocks != nullptr (m = 16 fast
 // path, HOP_SHIFTED) the kernel also leaves block partials of p^dagger out in c->partials.
 int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
@@ -316,7 +330,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   const bool fast = fast_hop(c, m);
   const bool gram = fast && gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
   const char* name = gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
-  if (gram) BCG_TRY(ensure_scratch(c));
+  if (fast) BCG_TRY(ensure_scratch(c));
   if (fast && can_overlap(c) && bcg::hop_can_split_tiles(m, c->lat)) {
     // pack -> post the exchange -> interior tiles (no ghost reads) -> wait for the exchange -> boundary tiles
     BCG_TRY(halo_field(c, in, /*split=*/true));
@@ -344,6 +358,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   }
   BCG_TRY(halo_field(c, in));
   if (fast) {
+    note_stencil_form(c, m, 0, bcg::HopWindow());
     ProfScope ps(c, name);
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                         p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune, 0);
@@ -470,6 +485,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   }
   BCG_TRY(halo_field(c, P));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
+    note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R});
     ProfScope ps(c, "hop_ring");
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
                                         0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});
@@ -662,6 +678,9 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_ROW_BLOCKS_C")) c->row_blocks_C = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_tune.patch_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_tune.blocks = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_SYNC")) c->hop_tune.sync.window = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_SYNC_LIMIT")) c->hop_tune.sync.limit_ticks = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);
   if (stream) {
@@ -691,6 +710,7 @@ int bcg_context_destroy(bcg_context* c) {
   if (c->halo_send) (void)hipFree(c->halo_send);
   if (c->halo_recv) (void)hipFree(c->halo_recv);
   if (c->partials) (void)hipFree(c->partials);
+  if (c->hop_tune.sync.counters) (void)hipFree(c->hop_tune.sync.counters);
   if (c->dev_mats) (void)hipFree(c->dev_mats);
   if (c->pin_mats) (void)hipHostFree(c->pin_mats);
   if (c->dev_gram) (void)hipFree(c->dev_gram);
@@ -741,6 +761,15 @@ int bcg_halo_buffers(bcg_context* c, void** send, void** recv, size_t* bytes_eac
   if (send) *send = c->halo_send;
   if (recv) *recv = c->halo_recv;
   if (bytes_each) *bytes_each = c->halo_bytes;
+  return BCG_OK;
+}
+
+// Tuning aid, not part of the interface (no declaration in include/): copy the Gram scratch buffer to the host.
+// Builds with -DBCG_HOP4_TRACE leave per-tile time stamps of the plain stencil there (tools/hop_drift.py).
+int bcg_debug_read_scratch(bcg_context* c, void* host, size_t bytes) {
+  if (!c || !host || !c->partials || bytes > c->partials_bytes) return BCG_ERR_INVALID;
+  BCG_TRY(stream_sync(c));
+  HIP_TRY(c, hipMemcpy(host, c->partials, bytes, hipMemcpyDeviceToHost));
   return BCG_OK;
 }
 
@@ -967,7 +996,12 @@ int bcg_field_thin_qr(bcg_field* y, double* R_out) {
 int bcg_gauge_create(bcg_context* c, bcg_gauge** out) {
   if (!c || !out) return BCG_ERR_INVALID;
   bcg_gauge* g = new bcg_gauge{c, nullptr, nullptr, false};
-  hipError_t e = hipMalloc(&g->U, static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2));
+  const size_t u_bytes = static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);
+  // experiment switch: links in memory the L2 does not cache (they are streamed; the L2 is for the field slices)
+  const char* unc = std::getenv("BCG_U_UNCACHED");
+  hipError_t e = (unc && std::atoi(unc) != 0)
+                     ? hipExtMallocWithFlags(reinterpret_cast<void**>(&g->U), u_bytes, hipDeviceMallocUncached)
+                     : hipMalloc(&g->U, u_bytes);
   if (e == hipSuccess && c->ghost_sites > 0) e = hipMalloc(&g->Ughost, static_cast<size_t>(c->ghost_sites) * 9 * sizeof(double2));
   if (e != hipSuccess) {
     if (g->U) (void)hipFree(g->U);

@@ -41,11 +41,31 @@ __device__ __forceinline__ double2 ld_nt(const double2* p) {
   const dv2 v = __builtin_nontemporal_load(reinterpret_cast<const dv2*>(p));
   return make_double2(v.x, v.y);
 }
+// link loads of the stencil: streamed (each link is needed by one tile, its backward copy by one more), so they are
+// marked non-temporal to leave the L2 to the field slices that are re-used (BCG_HOP4_U_NT=0: plain loads)
+#ifndef BCG_HOP4_U_NT
+#define BCG_HOP4_U_NT 0
+#endif
+__device__ __forceinline__ dv2 ld_link(const dv2* p) {
+#if BCG_HOP4_U_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+#ifndef BCG_HOP4_ST_SC1
+#define BCG_HOP4_ST_SC1 0
+#endif
 __device__ __forceinline__ void st_nt(double2* p, double2 v) {
   dv2 w;
   w.x = v.x;
   w.y = v.y;
+#if BCG_HOP4_ST_SC1
+  // write-through store that does not keep the line in the L2 (sc1), for output that is not read again by this kernel
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(reinterpret_cast<dv2*>(p)), "v"(w) : "memory");
+#else
   __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(p));
+#endif
 }
 
 // ---- coefficient matrices in LDS ------------------------------------------------------------------
@@ -582,6 +602,7 @@ __global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2*
 struct TileGeom {
   int x0b, x1, x2, x3;   // coordinates of the tile's first site
   int site0;             // its local site index
+  int edge;              // bit 0/1: the +x1/-x1 neighbour tile lies outside the tile's patch; bit 2/3: +x2/-x2
 };
 
 // Tile order: mixed-radix counter, fastest digit first:
@@ -593,7 +614,22 @@ struct TileGeom {
 struct HopWalk {
   int p0, p1, p2;        // patch extents (sites) in x0, x1, x2
   int xcd_split;
+  // Pacing of the blocks that share an XCD (k_hop4c only; nullptr = off).  The L2 re-use of the x3 walk needs those
+  // blocks on neighbouring slices, but nothing couples them and they spread over 7-15 slices (measured with
+  // -DBCG_HOP4_TRACE), so the slices they re-read have left the L2.  sync[class * stride + n] counts the blocks of a
+  // class that finished their n-th tile; a block starts tile n only when all of them finished tile n - window (bounded
+  // wait: after `sync_limit` ticks of the 100 MHz clock it stops pacing, so a block that is not resident cannot hang the rest).
+  unsigned* sync;
+  int sync_window, sync_stride, sync_limit;
 };
+
+// Pacing counters are read with the same read-modify-write unit that increments them (an add of 0): the blocks of a
+// class share an XCD and so an L2, where those atomics execute; a device-scope LOAD instead goes past the L2 and took
+// microseconds per tile (measured: the stencil ran 2x slower).
+// `zero` is a run-time 0: a literal would let the compiler turn the add into exactly that load.
+__device__ __forceinline__ unsigned read_counter(unsigned* ctr, unsigned zero) {
+  return __hip_atomic_fetch_add(ctr, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct Digits {
   int d0, d1, d2, d3, d4, d5, d6;
@@ -636,6 +672,7 @@ __device__ __forceinline__ TileGeom geom_of(const Digits& d, int r0, int p1, int
   g.x2 = d.d6 * p2 + d.d2;
   g.x3 = x3_lo + d.d3;
   g.site0 = g.x0b + L0 * (g.x1 + L1 * (g.x2 + L2 * g.x3));
+  g.edge = (d.d1 == p1 - 1 ? 1 : 0) | (d.d1 == 0 ? 2 : 0) | (d.d2 == p2 - 1 ? 4 : 0) | (d.d2 == 0 ? 8 : 0);
   return g;
 }
 
@@ -645,7 +682,7 @@ __device__ __forceinline__ void fetch_fwd(const double2* __restrict__ fsrc, int 
 #pragma unroll
   for (int k = 0; k < RF; ++k) {
     const int e = tid + 256 * k;
-    if (e < SPB * 36) rf[k] = *reinterpret_cast<const dv2*>(fsrc + e);
+    if (e < SPB * 36) rf[k] = ld_link(reinterpret_cast<const dv2*>(fsrc + e));
   }
 }
 
@@ -665,7 +702,7 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
       if (xm > 0) src = U + ((static_cast<int64_t>(site0) + s - Sm) * 4 + mu) * 9;
       else if (!spm) src = U + ((static_cast<int64_t>(site0) + s + static_cast<int64_t>(Lm - 1) * Sm) * 4 + mu) * 9;
       else src = Ughost + (gm + fi0 + s) * 9;
-      rb[k] = *reinterpret_cast<const dv2*>(src + c9);
+      rb[k] = ld_link(reinterpret_cast<const dv2*>(src + c9));
     }
   }
 }
@@ -675,8 +712,14 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
 // of 2 waves per SIMD in __launch_bounds__ costs 1.5 ms on both, so: CARRY = GRAM, plain __launch_bounds__(256).
 // CLS selects the tiles a launch processes: 0 all, 1 interior only (no site of the tile reads a ghost), 2 boundary only.
 // Interior and boundary launches bracket the halo exchange so that it overlaps the interior arithmetic.
+#ifndef BCG_HOP4_ATTR
+#define BCG_HOP4_ATTR
+#endif
+#ifndef BCG_HOP4_SCHED
+#define BCG_HOP4_SCHED 0
+#endif
 template <int M, int MODE, bool GRAM, bool NT, int CLS, bool RING>
-__global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
+__global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, const double2* __restrict__ U,
                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                               const double2* __restrict__ ghost, double2* __restrict__ out,
                                               const double2* __restrict__ p, double c0,
@@ -755,7 +798,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
       if ((g).x0b > 0) src = U + (static_cast<int64_t>((g).site0) - 1) * 36;                                      \
       else if (!sp0) src = U + (static_cast<int64_t>((g).site0) + L0 - 1) * 36;                                   \
       else src = Ughost + (gm0 + ((g).x1 + L1 * ((g).x2 + L2 * (g).x3))) * 9;                                     \
-      rx = *reinterpret_cast<const dv2*>(src + tid);                                                              \
+      rx = ld_link(reinterpret_cast<const dv2*>(src + tid));                                                      \
     }                                                                                                             \
     fetch_back<SPB, RBM>(1, (g).x1, L1, S1, sp1, gm1, (g).x0b + L0 * ((g).x2 + L2 * (g).x3), (g).site0, U, Ughost, tid, rb1); \
     fetch_back<SPB, RBM>(2, (g).x2, L2, S2, sp2, gm2, (g).x0b + L0 * ((g).x1 + L1 * (g).x3), (g).site0, U, Ughost, tid, rb2); \
@@ -788,6 +831,9 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   }
   if (have) BCG_FETCH_LINKS(g, false)
   int stage = 0;
+#ifdef BCG_HOP4_TRACE
+  int trace_n = 0;
+#endif
   int site_m1 = -1;          // site0 of the previous tile of this block
   int fsite_m1 = -1, fsite_m2 = -1;  // first site of the +x3 neighbour tile loaded 1 and 2 steps ago (-1: ghost)
   bool carry_u3 = false;     // this tile's U_3(x-3) is the previous tile's forward link
@@ -812,6 +858,17 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
       }
     }
     __syncthreads();
+#ifdef BCG_HOP4_TRACE
+    // drift study: time stamp (100 MHz) and x3 of every tile-step of every block, in the Gram scratch buffer
+    if (tid == 0 && !GRAM && partials) {
+      long long* tr = reinterpret_cast<long long*>(partials) + static_cast<int64_t>(blockIdx.x) * 4096;
+      const int n = trace_n++;
+      if (n < 2048) {
+        tr[2 * n] = wall_clock64();
+        tr[2 * n + 1] = g.site0;
+      }
+    }
+#endif
     const TileGeom cur = g;
     const bool cur_carry_u3 = carry_u3;
     have = next_tile(g);
@@ -868,6 +925,28 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
     const bool carry_b3 = CARRY_B3 && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
     const int fsite_now = (cur.x3 + 1 < L3) ? cur.site0 + S3 : (sp3 ? -1 : cur.site0 - (L3 - 1) * S3);
     double2 f[4][3], bk[4][3];
+#ifndef BCG_HOP4_HALO_NT
+#define BCG_HOP4_HALO_NT 0
+#endif
+#if BCG_HOP4_HALO_NT
+    // x1/x2 neighbours outside the patch are needed once per sweep: stream them past the L2 (uniform branches)
+#define BCG_LD3(DST, SRC, COND)                                                  \
+  if (COND) {                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) DST[k] = ld_nt(SRC + k * M + j); \
+  } else {                                                                       \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) DST[k] = SRC[k * M + j];       \
+  }
+    BCG_LD3(f[1], nf1, cur.edge & 1)
+    BCG_LD3(bk[1], nb1, cur.edge & 2)
+    BCG_LD3(f[2], nf2, cur.edge & 4)
+    BCG_LD3(bk[2], nb2, cur.edge & 8)
+#undef BCG_LD3
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
+      f[3][k] = nf3[k * M + j];
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
@@ -875,6 +954,7 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
       f[2][k] = nf2[k * M + j]; bk[2][k] = nb2[k * M + j];
       f[3][k] = nf3[k * M + j];
     }
+#endif
     if (carry_b3) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) bk[3][k] = make_double2(h2[k].x, h2[k].y);
@@ -899,6 +979,9 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
 #pragma unroll
       for (int r = 0; r < 3; ++r) pv[r] = NT ? ld_nt(p + o0 + r * M) : p[o0 + r * M];
     }
+#if BCG_HOP4_SCHED
+    __builtin_amdgcn_sched_barrier(0);  // keep every neighbour load ahead of the arithmetic (memory-level parallelism)
+#endif
     double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
     const int par1 = x0 + og0, par2 = par1 + cur.x1 + og1, par3 = par2 + cur.x2 + og2;
 #pragma unroll
@@ -943,6 +1026,309 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
 #undef BCG_FETCH_LINKS
   if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// k_hop4c: the patch walk of k_hop4 written as what it is -- every block owns one (x0 tile, x1, x2) column of its
+// patch and sweeps x3 -- so that nothing per tile needs vector address arithmetic or the mixed-radix counter:
+//   * the eight neighbour rows of a tile are wave-uniform byte pointers (SGPR pairs) recomputed from per-column
+//     constants by a few scalar instructions; a lane adds one constant 32-bit offset (site-in-tile, rhs), i.e.
+//     `global_load_dwordx4 v, v_off, s[base:base+1] offset:colour` with no VALU in front of it;
+//   * the x0 neighbours use the same row pointer shifted by one site; at the ends of a row the edge lane's offset
+//     is bent to the periodic image (a per-column choice of the offset register), or patched from the ghost face;
+//   * the blocks of an XCD are paced along x3 (HopWalk::sync) so that the slices they share stay in its L2.
+// Requirements (checked by the launcher, else k_hop4 runs): patch walk with one block per tile of a patch slice.
+// The per-tile instruction count drops from ~1100 to ~600 per wave; a wave issues at most one instruction every
+// four cycles, so at 2 waves per SIMD that count, not the arithmetic, was the floor of k_hop4.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld_sv(const char* __restrict__ sbase, unsigned voff, int imm) {
+  return *reinterpret_cast<const double2*>(sbase + voff + imm);
+}
+
+template <int M, int MODE, bool GRAM, bool RING>
+__global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __restrict__ U,
+                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                               const double2* __restrict__ ghost, double2* __restrict__ out,
+                                               const double2* __restrict__ p, double c0,
+                                               double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+  static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
+  constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
+  constexpr int SPW = 64 / M;
+  constexpr int SPB = 4 * SPW;
+  constexpr int NW = 4;
+  constexpr int NF = (SPB + 1) * 36;
+  constexpr int NB = 3 * SPB * 9;
+  constexpr int STAGE = NF + NB;
+  constexpr int RF = (SPB * 36 + 255) / 256;
+  constexpr int RBM = (SPB * 9 + 255) / 256;
+  constexpr int RB = 3 * M * 16;  // bytes of one site row of a field
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double2* Ls = reinterpret_cast<double2*>(smem);  // [2][STAGE] link images
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sl = wave * SPW + lane / M;
+  const int j = lane % M;
+  const unsigned voff = static_cast<unsigned>((sl * 3 * M + j) * 16);  // this lane's byte offset inside a tile row
+  const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
+  const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
+  const int sp0 = lat.split[0], sp1 = lat.split[1], sp2 = lat.split[2], sp3 = lat.split[3];
+  const int gm0 = static_cast<int>(lat.ghost_off[0][0]), gp0 = static_cast<int>(lat.ghost_off[0][1]);
+  const int gm1 = static_cast<int>(lat.ghost_off[1][0]), gp1 = static_cast<int>(lat.ghost_off[1][1]);
+  const int gm2 = static_cast<int>(lat.ghost_off[2][0]), gp2 = static_cast<int>(lat.ghost_off[2][1]);
+  const int gm3 = static_cast<int>(lat.ghost_off[3][0]), gp3 = static_cast<int>(lat.ghost_off[3][1]);
+  const int og0 = lat.origin[0], og1 = lat.origin[1], og2 = lat.origin[2];
+  const char* const inb = reinterpret_cast<const char*>(in);
+  const char* const ghb = reinterpret_cast<const char*>(ghost);
+  GramAcc<16> G;
+  if (GRAM) gram_zero(G);
+
+  // ---- this block's column inside a patch, and the patches of its XCD class
+  const int r0 = hw.p0 / SPB, r1 = hw.p1, r4 = L0 / hw.p0, r5 = L1 / hw.p1, r6 = L2 / hw.p2;
+  const int cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int d0 = idx % r0, d1 = (idx / r0) % r1, d2 = idx / (r0 * r1);
+  const int ppc = (r4 * r5 * r6) >> 3;
+  const int x3_end = win.x3_lo + win.x3_n;
+
+  dv2 rf[RF], rx, rb1[RBM], rb2[RBM], rb3[RBM];
+  rx = dv2{0.0, 0.0};
+#define BCG_FETCH_LINKS(g)                                                                                        \
+  {                                                                                                               \
+    fetch_fwd<SPB, RF>(U + static_cast<int64_t>((g).site0) * 36, tid, rf);                                        \
+    if (tid < 9) {                                                                                                \
+      const double2* src;                                                                                         \
+      if ((g).x0b > 0) src = U + (static_cast<int64_t>((g).site0) - 1) * 36;                                      \
+      else if (!sp0) src = U + (static_cast<int64_t>((g).site0) + L0 - 1) * 36;                                   \
+      else src = Ughost + (static_cast<int64_t>(gm0) + ((g).x1 + L1 * ((g).x2 + L2 * (g).x3))) * 9;               \
+      rx = ld_link(reinterpret_cast<const dv2*>(src + tid));                                                      \
+    }                                                                                                             \
+    fetch_back<SPB, RBM>(1, (g).x1, L1, S1, sp1, gm1, (g).x0b + L0 * ((g).x2 + L2 * (g).x3), (g).site0, U, Ughost, tid, rb1); \
+    fetch_back<SPB, RBM>(2, (g).x2, L2, S2, sp2, gm2, (g).x0b + L0 * ((g).x1 + L1 * (g).x3), (g).site0, U, Ughost, tid, rb2); \
+    fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
+  }
+  int stage = 0;
+  int step_n = 0;     // tiles this block has started
+  bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
+  const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
+  unsigned seen1 = 0, seen2 = 0;
+  const unsigned per = gridDim.x >> 3;
+
+  for (int pi = cls * ppc; pi < (cls + 1) * ppc; ++pi) {
+    const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
+    const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
+    const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
+    // ---- per-column constants of the six in-slice neighbour rows: site at x3 = 0, site stride per slice, buffer.
+    // Field rows move by S3 per slice (by ring slots in capacity mode), ghost rows by the face's x3 stride.
+#define BCG_COL_DIR(XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AF, SF, KF, AB, SB, KB)                         \
+  int AF, SF, AB, SB;                                                                                     \
+  bool KF, KB;                                                                                            \
+  if ((XM) + 1 < (LM)) { AF = col + (SM); SF = S3; KF = false; }                                          \
+  else if (!(SPM)) { AF = col - ((LM) - 1) * (SM); SF = S3; KF = false; }                                 \
+  else { AF = (GPL) + (FIDX); SF = (FSTR); KF = true; }                                                   \
+  if ((XM) > 0) { AB = col - (SM); SB = S3; KB = false; }                                                 \
+  else if (!(SPM)) { AB = col + ((LM) - 1) * (SM); SB = S3; KB = false; }                                 \
+  else { AB = (GMN) + (FIDX); SB = (FSTR); KB = true; }
+    BCG_COL_DIR(x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_f1, s_f1, k_f1, a_b1, s_b1, k_b1)
+    BCG_COL_DIR(x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_f2, s_f2, k_f2, a_b2, s_b2, k_b2)
+#undef BCG_COL_DIR
+    // direction 0: the row itself, shifted by one site; at the row ends the edge lane is bent to the periodic image
+    const bool row_end = x0b + SPB == L0, row_start = x0b == 0;
+    const bool gh0p = row_end && sp0, gh0m = row_start && sp0;
+    int shift_p = 1, shift_m = -1;  // sites
+    unsigned voff_p = voff, voff_m = voff;
+    if (row_end) {
+      if (!sp0) { shift_p = 1 - L0; voff_p = (sl == SPB - 1) ? voff : voff + static_cast<unsigned>(L0) * RB; }
+      else voff_p = (sl == SPB - 1) ? voff - RB : voff;   // edge lane: any valid row, replaced from the ghost face
+    }
+    if (row_start) {
+      if (!sp0) voff_m = (sl == 0) ? voff + static_cast<unsigned>(L0) * RB : voff;
+      else voff_m = (sl == 0) ? voff + RB : voff;
+    }
+    int slot = RING ? win.x3_lo % win.ring : 0;
+    TileGeom g;
+    g.x0b = x0b; g.x1 = x1; g.x2 = x2; g.x3 = win.x3_lo; g.site0 = col + win.x3_lo * S3; g.edge = 0;
+    BCG_FETCH_LINKS(g)  // first tile of the column: not overlapped (once per sweep)
+    for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
+      {  // park the links fetched for this tile in the current LDS stage
+        dv2* Lf = reinterpret_cast<dv2*>(Ls + stage * STAGE);
+        dv2* Lb = Lf + NF;
+#pragma unroll
+        for (int k = 0; k < RF; ++k) {
+          const int e = tid + 256 * k;
+          if (e < SPB * 36) Lf[36 + e] = rf[k];
+        }
+        if (tid < 9) Lf[tid] = rx;
+#pragma unroll
+        for (int k = 0; k < RBM; ++k) {
+          const int e = tid + 256 * k;
+          if (e < SPB * 9) {
+            Lb[e] = rb1[k];
+            Lb[SPB * 9 + e] = rb2[k];
+            Lb[2 * SPB * 9 + e] = rb3[k];
+          }
+        }
+      }
+      if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
+        const int need = step_n - hw.sync_window;
+        if (need >= 0 && seen2 < per) {  // the count read two tiles ago was short: poll
+          unsigned* ctr = hw.sync + cls * hw.sync_stride + need;
+          const long long t0 = wall_clock64();
+          while (read_counter(ctr, zero_rt) < per) {
+            if (wall_clock64() - t0 > hw.sync_limit) {
+              pace = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+      __syncthreads();
+#ifndef BCG_HOP4C_LINKPOS
+#define BCG_HOP4C_LINKPOS 0
+#endif
+#define BCG_PREFETCH_LINKS                                                                        \
+  if (x3 + 1 < x3_end) { /* the next slice's links: parked first thing in the next tile */        \
+    g.x3 = x3 + 1;                                                                                \
+    g.site0 += S3;                                                                                \
+    BCG_FETCH_LINKS(g)                                                                            \
+  }
+#if BCG_HOP4C_LINKPOS == 0
+      BCG_PREFETCH_LINKS
+#endif
+      const double2* Lf = Ls + stage * STAGE;
+      const double2* Lb = Lf + NF;
+      stage ^= 1;
+      // ---- the eight neighbour rows of this tile: scalar pointers
+      const int xf = RING_IN ? slot : x3;                       // where slice x3 of `in` lives
+      const int xfp = RING_IN ? (slot + 1 == win.ring ? 0 : slot + 1) : x3 + 1;
+      const int xfm = RING_IN ? (slot == 0 ? win.ring - 1 : slot - 1) : x3 - 1;
+#define BCG_ROW(A, S, K) ((K) ? ghb + static_cast<int64_t>((A) + x3 * (S)) * RB : inb + static_cast<int64_t>((A) + xf * (S)) * RB)
+      const char* const crow = inb + static_cast<int64_t>(col + xf * S3) * RB;
+      const char* const q_f0 = crow + static_cast<int64_t>(shift_p) * RB;
+      const char* const q_b0 = crow + static_cast<int64_t>(shift_m) * RB;
+      const char* const q_f1 = BCG_ROW(a_f1, s_f1, k_f1);
+      const char* const q_b1 = BCG_ROW(a_b1, s_b1, k_b1);
+      const char* const q_f2 = BCG_ROW(a_f2, s_f2, k_f2);
+      const char* const q_b2 = BCG_ROW(a_b2, s_b2, k_b2);
+#undef BCG_ROW
+      const char* q_f3;
+      const char* q_b3;
+      if (x3 + 1 < L3) q_f3 = inb + static_cast<int64_t>(col + xfp * S3) * RB;
+      else if (!sp3) q_f3 = inb + static_cast<int64_t>(col) * RB;  // slice 0 (slot 0: ring | L3)
+      else q_f3 = ghb + static_cast<int64_t>(gp3 + col) * RB;
+      if (x3 > 0) q_b3 = inb + static_cast<int64_t>(col + xfm * S3) * RB;
+      else if (!sp3) q_b3 = inb + static_cast<int64_t>(col + (RING_IN ? win.ring - 1 : L3 - 1) * S3) * RB;
+      else q_b3 = ghb + static_cast<int64_t>(gm3 + col) * RB;
+      double2 f[4][3], bk[4][3];
+      // loads and arithmetic are issued direction by direction, one direction ahead: at most two directions' rows
+      // (12 loads) are in flight per wave, which keeps the L2 working set of the resident blocks small
+      const char* const qf[4] = {q_f0, q_f1, q_f2, q_f3};
+      const char* const qb[4] = {q_b0, q_b1, q_b2, q_b3};
+#define BCG_LOAD_DIR(MU)                                                                   \
+  _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                          \
+    f[MU][k] = ld_sv(qf[MU], (MU) == 0 ? voff_p : voff, k * M * 16);                       \
+    bk[MU][k] = ld_sv(qb[MU], (MU) == 0 ? voff_m : voff, k * M * 16);                      \
+  }
+#ifndef BCG_HOP4C_AHEAD
+#define BCG_HOP4C_AHEAD 1
+#endif
+      BCG_LOAD_DIR(0)
+#if BCG_HOP4C_AHEAD == 2
+      BCG_LOAD_DIR(1)
+#endif
+      if (gh0p || gh0m) {  // direction 0 divided over ranks: the edge site of an end-of-row tile reads the ghost face
+        const int64_t f0 = x1 + L1 * (x2 + L2 * x3);
+        if (gh0p && sl == SPB - 1) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) f[0][k] = ghost[(gp0 + f0) * 3 * M + k * M + j];
+        }
+        if (gh0m && sl == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bk[0][k] = ghost[(gm0 + f0) * 3 * M + k * M + j];
+        }
+      }
+      const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
+      const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
+      char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col + slot * S3) : crow_site) * RB;
+      double2 pv[3];
+      // pacing: read now the counter the tile after next is checked against (see k_hop4)
+      seen2 = seen1;
+      if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window)
+        seen1 = read_counter(hw.sync + cls * hw.sync_stride + (step_n + 2 - hw.sync_window), zero_rt);
+      double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+      const int x0 = x0b + sl;
+      const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
+#pragma unroll
+      for (int mu = 0; mu < 4; ++mu) {
+#if BCG_HOP4C_AHEAD == 2
+        if (mu == 0) { BCG_LOAD_DIR(2) }
+        if (mu == 1) {
+#else
+        if (mu == 0) {
+          BCG_LOAD_DIR(1)
+#if BCG_HOP4C_LINKPOS == 1
+          BCG_PREFETCH_LINKS
+#endif
+        }
+        if (mu == 1) {
+          BCG_LOAD_DIR(2)
+#if BCG_HOP4C_LINKPOS == 2
+          BCG_PREFETCH_LINKS
+#endif
+        }
+        if (mu == 2) {
+#endif
+          // Vector memory returns in issue order, so what misses the L2 goes last: the new slice (+x3), then p.
+          // (The next tile's links also miss, but issued this late they are not back when that tile parks them: 15.4 ms.)
+          BCG_LOAD_DIR(3)
+          if (MODE == HOP_SHIFTED) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) pv[r] = ld_nt(reinterpret_cast<const double2*>(prow + voff + r * M * 16));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
+        const double eta = (par & 1) ? -1.0 : 1.0;
+        const double2* uf = Lf + (sl + 1) * 36 + mu * 9;
+        const double2* ub = mu == 0 ? Lf + sl * 36 : Lb + ((mu - 1) * SPB + sl) * 9;
+        double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const double2 u = uf[k * 3 + r];
+            t[r].x = fma(u.x, f[mu][k].x, t[r].x); t[r].x = fma(-u.y, f[mu][k].y, t[r].x);
+            t[r].y = fma(u.x, f[mu][k].y, t[r].y); t[r].y = fma(u.y, f[mu][k].x, t[r].y);
+            const double2 v = ub[r * 3 + k];
+            t[r].x = fma(-v.x, bk[mu][k].x, t[r].x); t[r].x = fma(-v.y, bk[mu][k].y, t[r].x);
+            t[r].y = fma(-v.x, bk[mu][k].y, t[r].y); t[r].y = fma(v.y, bk[mu][k].x, t[r].y);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          acc[r].x = fma(eta, t[r].x, acc[r].x);
+          acc[r].y = fma(eta, t[r].y, acc[r].y);
+        }
+      }
+      double2 tv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+        else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+        st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+      }
+      if (GRAM) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
+      }
+      if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
+        __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++step_n;
+      if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+    }
+  }
+#undef BCG_FETCH_LINKS
+  if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
+}
+
 
 inline int grid_tiles(int64_t ntiles, int per_block, int cap) {
   int64_t g = (ntiles + per_block - 1) / per_block;
@@ -1038,24 +1424,80 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
   return grid;
 }
 
+// What one launch of the specialised stencil will do (shared by the launcher and hop_kernel_form).
+struct HopPlan {
+  bool valid = false;
+  bool column = false;  // k_hop4c (column sweep, scalar row pointers) instead of k_hop4
+  int ntiles = 0, grid = 0;
+  HopWalk hw{};
+  HopWindow win{};
+};
+static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int cls, HopWindow win) {
+  HopPlan pl;
+  const int SPB = 4 * (64 / m);
+  const int walk = tune.patch_walk ? 3 : 0, p0 = tune.patch[0], p1 = tune.patch[1], p2 = tune.patch[2];
+  if (win.x3_n <= 0) win = HopWindow{0, lat.L[3], win.ring};
+  if (win.x3_lo < 0 || win.x3_lo + win.x3_n > lat.L[3]) return pl;
+  // ring addressing: whole tiles only (no interior/boundary split), direction 3 undivided, ring | L3
+  if (win.ring > 0 && (cls != 0 || lat.split[3] || win.ring < 3 || lat.L[3] % win.ring != 0)) return pl;
+  pl.win = win;
+  pl.ntiles = static_cast<int>(lat.V / lat.L[3] * win.x3_n / SPB);
+  const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
+                   lat.L[2] % p2 == 0 && pl.ntiles % 8 == 0 && max_blocks % 8 == 0 && pl.ntiles / 8 >= max_blocks / 8;
+  pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0};  // lexicographic = one patch
+  if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0};
+  pl.grid = pl.ntiles < max_blocks ? pl.ntiles : max_blocks;
+  if (pl.hw.xcd_split) pl.grid &= ~7;
+  // column form of the walk: one block per tile of a patch slice, whole patches per XCD class, all tiles in one launch
+  pl.column = tune.sync.column_walk && pl.hw.xcd_split && cls == 0 && pl.grid / 8 == (p0 / SPB) * p1 * p2 &&
+              ((lat.L[0] / p0) * (lat.L[1] / p1) * (lat.L[2] / p2)) % 8 == 0;
+  if (pl.column && tune.sync.window > 0 && tune.sync.counters != nullptr) {
+    const int steps = pl.ntiles / pl.grid;  // tiles per block (every block has the same number)
+    if (steps <= tune.sync.stride) {
+      pl.hw.sync = tune.sync.counters;
+      pl.hw.sync_window = tune.sync.window;
+      pl.hw.sync_stride = tune.sync.stride;
+      pl.hw.sync_limit = tune.sync.limit_ticks;
+    }
+  }
+  pl.valid = true;
+  return pl;
+}
+
 template <int M>
 static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
                        const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
-                       bool gram, int max_blocks, int walk, int p0, int p1, int p2, int cls, HopWindow win) {
+                       bool gram, int max_blocks, const HopTuning& tune, int cls, const HopWindow& win_in) {
   constexpr int SPB = 4 * (64 / M);
-  if (win.x3_n <= 0) win = HopWindow{0, lat.L[3], win.ring};
-  if (win.x3_lo < 0 || win.x3_lo + win.x3_n > lat.L[3]) return -1;
-  // ring addressing: whole tiles only (no interior/boundary split), direction 3 undivided, ring | L3
-  if (win.ring > 0 && (cls != 0 || lat.split[3] || win.ring < 3 || lat.L[3] % win.ring != 0)) return -1;
-  const int ntiles = static_cast<int>(lat.V / lat.L[3] * win.x3_n / SPB);
-  const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
-                   lat.L[2] % p2 == 0 && ntiles % 8 == 0 && max_blocks % 8 == 0 && ntiles / 8 >= max_blocks / 8;
-  HopWalk hw{lat.L[0], lat.L[1], lat.L[2], 0};  // lexicographic = one patch
-  if (ok3) hw = HopWalk{p0, p1, p2, 1};
-  int grid = ntiles < max_blocks ? ntiles : max_blocks;
-  if (hw.xcd_split) grid &= ~7;
-  const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
+  const HopPlan pl = plan_hop4(M, lat, max_blocks, tune, cls, win_in);
+  if (!pl.valid) return -1;
+  const int grid = pl.grid, ntiles = pl.ntiles;
+  const HopWalk hw = pl.hw;
+  const HopWindow win = pl.win;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
+  if (pl.column) {
+    if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
+    const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
+    const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+#define BCG_LAUNCH4C(MM, MD, GR, RG)                                                                                    \
+  do {                                                                                                                 \
+    allow_lds(k_hop4c<MM, MD, GR, RG>, lds);                                                                           \
+    hipLaunchKernelGGL((k_hop4c<MM, MD, GR, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0, \
+                       partials, hw, win);                                                                             \
+  } while (0)
+#define BCG_LAUNCH4C_R(MM, MD, GR)                       \
+  do {                                                   \
+    if (win.ring > 0) BCG_LAUNCH4C(MM, MD, GR, true);    \
+    else BCG_LAUNCH4C(MM, MD, GR, false);                \
+  } while (0)
+    if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4C_R(16, HOP_SHIFTED, true);
+    else if (mode == HOP_PLAIN) BCG_LAUNCH4C_R(M, HOP_PLAIN, false);
+    else BCG_LAUNCH4C_R(M, HOP_SHIFTED, false);
+#undef BCG_LAUNCH4C_R
+#undef BCG_LAUNCH4C
+    return grid;
+  }
+  const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
   // the streaming (non-temporal) form is the only one instantiated
 #define BCG_LAUNCH4(MM, MD, GR, CL, RG)                                                                                   \
@@ -1079,6 +1521,13 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   return grid;
 }
 
+int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win) {
+  if (!hop_can_split_tiles(m, lat)) return 0;
+  const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
+  const HopPlan pl = plan_hop4(m, lat, mb, tune, tile_class, win);
+  return !pl.valid ? -1 : (pl.column ? 2 : 1);
+}
+
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0,
                     double2* partials, bool gram, int max_blocks, const HopTuning& tune, int tile_class,
@@ -1086,12 +1535,10 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
   const int spb = 4 * (64 / m);
   // specialised 4-D kernel: tile = spb consecutive x0 sites of one row, 32-bit site arithmetic
   if (hop_can_split_tiles(m, lat)) {
-    const int walk = tune.patch_walk ? 3 : 0;
     const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
-    const int* pt = tune.patch;
-    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
-    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
-    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, walk, pt[0], pt[1], pt[2], tile_class, win);
+    if (m == 8) return launch_hop4<8>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
+    if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
+    return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
   }
   if (win.x3_n > 0 || win.ring > 0) return -1;  // x3 windows and ring addressing exist in the specialised kernel only
   if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles

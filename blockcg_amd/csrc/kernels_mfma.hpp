@@ -22,11 +22,22 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
                      int max_blocks);
+// Pacing counters of the specialised stencil (kernels_mfma.hip, HopWalk::sync); owned by the context.
+struct HopSync {
+  unsigned* counters = nullptr;  // 8 * stride, device memory
+  int stride = 0;                // tiles per block the buffer has room for
+  int window = 4;                // slices a block may run ahead of the slowest block of its XCD class (0 = no pacing);
+                                 // measured at 64^4: 2 -> 13.3 ms, 3 -> 11.0, 4..8 -> 10.9 (unpaced 13.4)
+  int limit_ticks = 5000;        // 100 MHz ticks (50 us) a block waits before it gives up pacing
+  bool column_walk = true;       // use k_hop4c (scalar row pointers, column sweep) where the walk allows it
+};
+
 // Tuning of the specialised 4-D stencil (defaults chosen by measurement at 64^4, m = 16).
 struct HopTuning {
   bool patch_walk = true;        // per-XCD patches swept along x3 (false: lexicographic tile order)
   int patch[3] = {16, 8, 8};     // patch extents in x0, x1, x2
   int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
+  HopSync sync;                  // pacing of the blocks of an XCD along x3
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
   int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
                                  // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
@@ -49,5 +60,7 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
                     const HopWindow& win = HopWindow());
 // true when launch_hop_fast can process interior (tile_class 1) and boundary (2) tiles in separate launches
 bool hop_can_split_tiles(int m, const LatticeDev& lat);
+// Which kernel launch_hop_fast will use: 0 general (k_hop_fast), 1 k_hop4 (tile counter), 2 k_hop4c (column sweep), -1 rejected
+int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win);
 
 }  // namespace bcg

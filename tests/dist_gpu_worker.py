@@ -27,7 +27,7 @@ def main():
     assert int(np.prod(grid)) == world
     nd = len(gdims)
     coords = coords_of(rank, grid)
-    comm = TorchDistComm(0)
+    comm = TorchDistComm(0, overlap=os.environ.get("BCG_TEST_OVERLAP", "1") == "1")
     ctx = bc.Context(gdims, device=0, grid=grid, coords=coords, stream=comm.stream_ptr)
     comm.attach(ctx)
     ctx.force_generic(generic)

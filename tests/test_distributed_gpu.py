@@ -24,13 +24,13 @@ CASES = [
 ]
 
 
-def _run_ranks(dims, grid, m, generic, ring=0):
+def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True):
     world = 1
     for g in grid:
         world *= g
     env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)),
                BCG_TEST_M=str(m), BCG_TEST_GENERIC="1" if generic else "0", BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1",
-               BCG_HOP_BLOCKS="8", BCG_HOP_PATCH="16,2,2")
+               BCG_HOP_BLOCKS=blocks, BCG_HOP_PATCH=patch, BCG_TEST_OVERLAP="1" if overlap else "0")
     port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
@@ -51,6 +51,21 @@ RING_CASES = [
     ([64, 4, 4, 8], [2, 1, 2, 1], 8, 8),     # m = 8, ring = L3
     ([16, 4, 4, 12], [2, 1, 1, 1], 32, 4),   # m = 32
 ]
+
+
+COLUMN_CASES = [
+    # local lattice 32x8x8x6 (m = 16) with 32 blocks and 16x2x2 patches: the column-sweep kernel (k_hop4c) with ghost faces
+    # in every direction; the exchange is not split, so the whole stencil is one launch
+    ([64, 8, 8, 6], [2, 1, 1, 1], 16, 0),     # x0 divided: edge lanes patched from the ghost face, U_0 ghost
+    ([32, 16, 8, 6], [1, 2, 1, 1], 16, 0),    # x1
+    ([32, 8, 16, 12], [1, 1, 2, 2], 16, 0),   # x2 and x3, 4 ranks
+    ([64, 16, 8, 6], [2, 2, 1, 1], 16, 3),    # x0, x1 and capacity mode
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,ring", COLUMN_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_domain_decomposed_solve_column_sweep(dims, grid, m, ring):
+    _run_ranks(dims, grid, m, False, ring, blocks="32", patch="16,2,2", overlap=False)
 
 
 @pytest.mark.parametrize("dims,grid,m,ring", RING_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))

@@ -472,3 +472,41 @@ def test_capacity_mode_arguments(bc):
     X = [bc.block_fermion_field(ctx, 4)]
     bc.SBCGrQ(X, B, D, [0.1], 1e-10, max_iterations=300)
     assert bc.true_residuals(X, B, D, [0.1]).max() < 2e-10
+
+
+@pytest.mark.parametrize("m,dims,patch,blocks", [(16, [32, 8, 8, 6], "16,2,2", "32"), (16, [64, 4, 8, 4], "32,2,2", "64"),
+                                                 (8, [64, 8, 8, 4], "32,2,2", "32"), (32, [16, 8, 8, 4], "8,2,2", "32")])
+@pytest.mark.parametrize("sync", ["0", "1", "4"])
+def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, monkeypatch):
+    """k_hop4c: one block per tile of a patch slice sweeping x3 with scalar row pointers, the blocks of an XCD class
+    paced by device counters (window 1 forces waits, 0 switches pacing off).  Operator, fused Gram product, a fixed
+    number of iterations and capacity mode against the oracle; the profile shows which kernel form ran."""
+    monkeypatch.setenv("BCG_HOP_PATCH", patch)
+    monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
+    monkeypatch.setenv("BCG_HOP_SYNC", sync)
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 71)
+    Bh = orc.fill_field(m, V, 72)
+    shifts, iters = [0.0, 0.05], 4
+    o = orc.sbcgrq(U, dims, 0.3, Bh, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters)
+    ref_op = orc.dirac_apply(U, dims, 0.3, Bh)
+    for ring in (0, 2 if dims[3] == 4 else 3):
+        if ring == 2:
+            ring = 4  # ring = L3
+        ctx = bc.Context(dims)
+        ctx.capacity_mode(ring)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, 0.3, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        out = bc.block_fermion_field(ctx, m)
+        D.op(out, B)
+        assert rel_err(out.download(), ref_op) < TOL_KERNEL
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        info = bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters, return_info=True)
+        for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+            assert rel_err(info["trace"][key], o["trace"][key]) < TOL_COEFF, key
+        for s in range(len(shifts)):
+            assert rel_err(X[s].download(), o["X"][s]) < 1e-10
+        prof = ctx.profile()
+        assert prof.get("stencil_form_k_hop4c", {}).get("count", 0) > 0, prof.keys()
+        assert "stencil_form_k_hop4" not in prof and "stencil_form_general" not in prof
