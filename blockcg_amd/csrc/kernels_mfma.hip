@@ -1435,7 +1435,8 @@ struct HopPlan {
 static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int cls, HopWindow win) {
   HopPlan pl;
   const int SPB = 4 * (64 / m);
-  const int walk = tune.patch_walk ? 3 : 0, p0 = tune.patch[0], p1 = tune.patch[1], p2 = tune.patch[2];
+  // patch extent in x0: one tile unless set (a patch slice then has p1*p2 = 64 tiles = the blocks of an XCD at every width)
+  const int walk = tune.patch_walk ? 3 : 0, p0 = tune.patch[0] > 0 ? tune.patch[0] : SPB, p1 = tune.patch[1], p2 = tune.patch[2];
   if (win.x3_n <= 0) win = HopWindow{0, lat.L[3], win.ring};
   if (win.x3_lo < 0 || win.x3_lo + win.x3_n > lat.L[3]) return pl;
   // ring addressing: whole tiles only (no interior/boundary split), direction 3 undivided, ring | L3

@@ -35,7 +35,7 @@ struct HopSync {
 // Tuning of the specialised 4-D stencil (defaults chosen by measurement at 64^4, m = 16).
 struct HopTuning {
   bool patch_walk = true;        // per-XCD patches swept along x3 (false: lexicographic tile order)
-  int patch[3] = {16, 8, 8};     // patch extents in x0, x1, x2
+  int patch[3] = {0, 8, 8};      // patch extents in x0, x1, x2; 0 in x0 = one tile (16 sites at m = 16)
   int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
   HopSync sync;                  // pacing of the blocks of an XCD along x3
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
