@@ -331,19 +331,23 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   const bool gram = fast && gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
   const char* name = gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
   if (fast) BCG_TRY(ensure_scratch(c));
-  if (fast && can_overlap(c) && bcg::hop_can_split_tiles(m, c->lat)) {
+  // BCG_FORCE_TILE_CLASSES=1 (tuning aid): take the two-launch path on an undivided lattice too, where every tile is
+  // an interior one, to time the interior-class kernel on one GPU
+  static const bool force_classes = std::getenv("BCG_FORCE_TILE_CLASSES") && std::atoi(std::getenv("BCG_FORCE_TILE_CLASSES")) != 0;
+  if (fast && bcg::hop_can_split_tiles(m, c->lat) && (can_overlap(c) || (force_classes && !c->distributed))) {
     // pack -> post the exchange -> interior tiles (no ghost reads) -> wait for the exchange -> boundary tiles
-    BCG_TRY(halo_field(c, in, /*split=*/true));
+    if (c->distributed) BCG_TRY(halo_field(c, in, /*split=*/true));
     bcg::HopTuning tune = c->hop_tune;
     tune.blocks = tune.blocks_overlap;  // leave some CUs to the transport's kernels while it runs
     int nb1, nb2;
+    note_stencil_form(c, m, 1, bcg::HopWindow());
     {
       ProfScope ps(c, name);
       nb1 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                  p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, /*interior*/ 1);
     }
     BCG_TRY(check_launch(c, name));
-    {
+    if (c->distributed) {
       ProfScope ps(c, "halo_exchange_end");
       BCG_TRY(exchange_end(c));
     }

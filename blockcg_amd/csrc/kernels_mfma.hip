@@ -1044,12 +1044,12 @@ __device__ __forceinline__ double2 ld_sv(const char* __restrict__ sbase, unsigne
   return *reinterpret_cast<const double2*>(sbase + voff + imm);
 }
 
-template <int M, int MODE, bool GRAM, bool RING>
-__global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __restrict__ U,
-                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
-                                               const double2* __restrict__ ghost, double2* __restrict__ out,
-                                               const double2* __restrict__ p, double c0,
-                                               double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+template <int M, int MODE, bool GRAM, int CLS, bool RING>
+__device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2* __restrict__ U,
+                                           const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                           const double2* __restrict__ ghost, double2* __restrict__ out,
+                                           const double2* __restrict__ p, double c0, double2* __restrict__ partials,
+                                           const HopWalk& hw, const HopWindow& win) {
   static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
   constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
@@ -1105,16 +1105,25 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
     fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
   }
   int stage = 0;
-  int step_n = 0;     // tiles this block has started
   bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
   const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
-  unsigned seen1 = 0, seen2 = 0;
+  unsigned seen1 = 0, seen2 = 0;   // thread 0: counters read one and two processed tiles ago ...
+  int seen1_idx = -1, seen2_idx = -1;  // ... and which tile numbers they belong to
   const unsigned per = gridDim.x >> 3;
+  // Tile classes (CLS 1: interior only, 2: boundary only; see k_hop4).  Every block still walks every tile number of
+  // its class's sequence and counts the skipped ones as done, so the pacing counters keep their meaning.
 
   for (int pi = cls * ppc; pi < (cls + 1) * ppc; ++pi) {
     const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
     const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
     const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
+    const bool col_bnd = (sp0 && (x0b == 0 || x0b + SPB == L0)) || (sp1 && (x1 == 0 || x1 == L1 - 1)) ||
+                         (sp2 && (x2 == 0 || x2 == L2 - 1));
+    auto wanted = [&](int x3) -> bool {
+      if (CLS == 0) return true;
+      return (col_bnd || (sp3 && (x3 == 0 || x3 == L3 - 1))) == (CLS == 2);
+    };
+    const int vs0 = (pi - cls * ppc) * win.x3_n - win.x3_lo;  // tile number of slice x3 in this block's sequence: vs0 + x3
     // ---- per-column constants of the six in-slice neighbour rows: site at x3 = 0, site stride per slice, buffer.
     // Field rows move by S3 per slice (by ring slots in capacity mode), ghost rows by the face's x3 stride.
 #define BCG_COL_DIR(XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AF, SF, KF, AB, SB, KB)                         \
@@ -1145,8 +1154,20 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
     int slot = RING ? win.x3_lo % win.ring : 0;
     TileGeom g;
     g.x0b = x0b; g.x1 = x1; g.x2 = x2; g.x3 = win.x3_lo; g.site0 = col + win.x3_lo * S3; g.edge = 0;
-    BCG_FETCH_LINKS(g)  // first tile of the column: not overlapped (once per sweep)
+    int links_for = -1;  // slice whose links are in the prefetch registers
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
+      const int step_n = vs0 + x3;
+      if (!wanted(x3)) {  // not this launch's tile: count it as done
+        if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
+          __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+        continue;
+      }
+      if (links_for != x3) {  // first tile of a run: not overlapped
+        g.x3 = x3;
+        g.site0 = col + x3 * S3;
+        BCG_FETCH_LINKS(g)
+      }
       {  // park the links fetched for this tile in the current LDS stage
         dv2* Lf = reinterpret_cast<dv2*>(Ls + stage * STAGE);
         dv2* Lb = Lf + NF;
@@ -1168,7 +1189,8 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
       }
       if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
         const int need = step_n - hw.sync_window;
-        if (need >= 0 && seen2 < per) {  // the count read two tiles ago was short: poll
+        const unsigned known = seen2_idx == need ? seen2 : (seen1_idx == need ? seen1 : 0u);
+        if (need >= 0 && known < per) {  // the count read ahead was short (or there is none): poll
           unsigned* ctr = hw.sync + cls * hw.sync_stride + need;
           const long long t0 = wall_clock64();
           while (read_counter(ctr, zero_rt) < per) {
@@ -1185,10 +1207,15 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
 #define BCG_HOP4C_LINKPOS 0
 #endif
 #define BCG_PREFETCH_LINKS                                                                        \
-  if (x3 + 1 < x3_end) { /* the next slice's links: parked first thing in the next tile */        \
-    g.x3 = x3 + 1;                                                                                \
-    g.site0 += S3;                                                                                \
-    BCG_FETCH_LINKS(g)                                                                            \
+  {                                                                                               \
+    int nx = x3 + 1; /* the next tile of this launch in the column: its links are parked first thing there */ \
+    while (CLS != 0 && nx < x3_end && !wanted(nx)) ++nx;                                          \
+    if (nx < x3_end) {                                                                            \
+      g.x3 = nx;                                                                                  \
+      g.site0 = col + nx * S3;                                                                    \
+      BCG_FETCH_LINKS(g)                                                                          \
+      links_for = nx;                                                                             \
+    }                                                                                             \
   }
 #if BCG_HOP4C_LINKPOS == 0
       BCG_PREFETCH_LINKS
@@ -1251,8 +1278,11 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
       double2 pv[3];
       // pacing: read now the counter the tile after next is checked against (see k_hop4)
       seen2 = seen1;
-      if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window)
-        seen1 = read_counter(hw.sync + cls * hw.sync_stride + (step_n + 2 - hw.sync_window), zero_rt);
+      seen2_idx = seen1_idx;
+      if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window) {
+        seen1_idx = step_n + 2 - hw.sync_window;
+        seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
+      }
       double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
       const int x0 = x0b + sl;
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
@@ -1321,12 +1351,30 @@ __global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __
       }
       if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
         __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ++step_n;
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
     }
   }
 #undef BCG_FETCH_LINKS
   if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
+}
+
+// Entry points.  The interior-class fused-Gram variant (and those of m = 8) need 260-280 VGPRs as scheduled by default,
+// which would leave one wave per SIMD; they are compiled for two.  The same cap on the other variants changes their instruction schedule and
+// costs 3 ms at 64^4 (measured), so it is applied only there.
+template <int M, int MODE, bool GRAM, int CLS, bool RING>
+__global__ void __launch_bounds__(256) k_hop4c(LatticeDev lat, const double2* __restrict__ U,
+                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                               const double2* __restrict__ ghost, double2* __restrict__ out,
+                                               const double2* __restrict__ p, double c0,
+                                               double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+  hop4c_body<M, MODE, GRAM, CLS, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
+}
+template <int M, int MODE, bool GRAM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_hop4c_interior(LatticeDev lat, const double2* __restrict__ U, const double2* __restrict__ Ughost,
+                 const double2* __restrict__ in, const double2* __restrict__ ghost, double2* __restrict__ out,
+                 const double2* __restrict__ p, double c0, double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+  hop4c_body<M, MODE, GRAM, 1, false>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
 }
 
 
@@ -1449,8 +1497,8 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
   if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0};
   pl.grid = pl.ntiles < max_blocks ? pl.ntiles : max_blocks;
   if (pl.hw.xcd_split) pl.grid &= ~7;
-  // column form of the walk: one block per tile of a patch slice, whole patches per XCD class, all tiles in one launch
-  pl.column = tune.sync.column_walk && pl.hw.xcd_split && cls == 0 && pl.grid / 8 == (p0 / SPB) * p1 * p2 &&
+  // column form of the walk: one block per tile of a patch slice, whole patches per XCD class
+  pl.column = tune.sync.column_walk && pl.hw.xcd_split && pl.grid / 8 == (p0 / SPB) * p1 * p2 &&
               ((lat.L[0] / p0) * (lat.L[1] / p1) * (lat.L[2] / p2)) % 8 == 0;
   if (pl.column && tune.sync.window > 0 && tune.sync.counters != nullptr) {
     const int steps = pl.ntiles / pl.grid;  // tiles per block (every block has the same number)
@@ -1480,16 +1528,22 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
     if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
     const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
     const size_t lds = lds_u > lds_g ? lds_u : lds_g;
-#define BCG_LAUNCH4C(MM, MD, GR, RG)                                                                                    \
+#define BCG_LAUNCH4C(MM, MD, GR, CL, RG)                                                                                \
   do {                                                                                                                 \
-    allow_lds(k_hop4c<MM, MD, GR, RG>, lds);                                                                           \
-    hipLaunchKernelGGL((k_hop4c<MM, MD, GR, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, c0, \
-                       partials, hw, win);                                                                             \
+    allow_lds(k_hop4c<MM, MD, GR, CL, RG>, lds);                                                                       \
+    hipLaunchKernelGGL((k_hop4c<MM, MD, GR, CL, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                       c0, partials, hw, win);                                                                         \
   } while (0)
-#define BCG_LAUNCH4C_R(MM, MD, GR)                       \
-  do {                                                   \
-    if (win.ring > 0) BCG_LAUNCH4C(MM, MD, GR, true);    \
-    else BCG_LAUNCH4C(MM, MD, GR, false);                \
+#define BCG_LAUNCH4C_R(MM, MD, GR)                          \
+  do {                                                      \
+    if (win.ring > 0) BCG_LAUNCH4C(MM, MD, GR, 0, true);    \
+    else if (cls == 1 && (GR || MM == 8)) { /* interior variants over 256 VGPRs: register-capped entry point */ \
+      allow_lds(k_hop4c_interior<MM, MD, GR>, lds);         \
+      hipLaunchKernelGGL((k_hop4c_interior<MM, MD, GR>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                         c0, partials, hw, win);            \
+    } else if (cls == 1) BCG_LAUNCH4C(MM, MD, GR, 1, false); \
+    else if (cls == 2) BCG_LAUNCH4C(MM, MD, GR, 2, false);  \
+    else BCG_LAUNCH4C(MM, MD, GR, 0, false);                \
   } while (0)
     if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4C_R(16, HOP_SHIFTED, true);
     else if (mode == HOP_PLAIN) BCG_LAUNCH4C_R(M, HOP_PLAIN, false);

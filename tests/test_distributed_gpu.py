@@ -63,9 +63,14 @@ COLUMN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("overlap", [False, True], ids=["whole", "interior+boundary"])
 @pytest.mark.parametrize("dims,grid,m,ring", COLUMN_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
-def test_domain_decomposed_solve_column_sweep(dims, grid, m, ring):
-    _run_ranks(dims, grid, m, False, ring, blocks="32", patch="16,2,2", overlap=False)
+def test_domain_decomposed_solve_column_sweep(dims, grid, m, ring, overlap):
+    """overlap: the split exchange, i.e. the interior and the boundary tile classes of the column-sweep kernel in two
+    launches (capacity mode never splits)."""
+    if overlap and ring:
+        pytest.skip("capacity mode does not use the split exchange")
+    _run_ranks(dims, grid, m, False, ring, blocks="32", patch="16,2,2", overlap=overlap)
 
 
 @pytest.mark.parametrize("dims,grid,m,ring", RING_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
