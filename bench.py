@@ -110,6 +110,9 @@ def main():
         backend = os.environ.get("BCG_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         dist.init_process_group(backend=backend, device_id=torch.device("cuda", device) if backend == "nccl" else None)
         grid = grid_for(world, ndim, keep_last=args.capacity > 0)
+        if os.environ.get("BCG_BENCH_GRID"):  # rehearsal aid: an explicit process grid, e.g. "1,1,2,1"
+            grid = [int(x) for x in os.environ["BCG_BENCH_GRID"].split(",")]
+            assert len(grid) == ndim and int(__import__("math").prod(grid)) == world
         coords = coords_of(rank, grid)
         comm = TorchDistComm(device)
         gdims = [l * g for l, g in zip(args.local_dims, grid)]

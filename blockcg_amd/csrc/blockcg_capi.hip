@@ -311,6 +311,34 @@ inline bool fast_rmul(const bcg_context* c, int m) { return !c->force_generic &&
 inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
 constexpr int kFastBlocks = 1024;  // persistent-style grids: 4 blocks per CU
 
+// The boundary tiles (a site of the tile has a neighbour in a ghost face) of the tiling with `spb` sites per tile, in
+// lexicographic order; built once per tile length.  The boundary launch deals them to its blocks round-robin.
+int boundary_tile_list(bcg_context* c, int spb, const int** list, int* n) {
+  auto it = c->boundary_tiles.find(spb);
+  if (it == c->boundary_tiles.end()) {
+    const bcg::LatticeDev& L = c->lat;
+    std::vector<int> tiles;
+    for (int x3 = 0; x3 < L.L[3]; ++x3)
+      for (int x2 = 0; x2 < L.L[2]; ++x2)
+        for (int x1 = 0; x1 < L.L[1]; ++x1) {
+          const bool b123 = (L.split[1] && (x1 == 0 || x1 == L.L[1] - 1)) || (L.split[2] && (x2 == 0 || x2 == L.L[2] - 1)) ||
+                            (L.split[3] && (x3 == 0 || x3 == L.L[3] - 1));
+          for (int x0b = 0; x0b < L.L[0]; x0b += spb)
+            if (b123 || (L.split[0] && (x0b == 0 || x0b + spb == L.L[0])))
+              tiles.push_back(x0b + L.L[0] * (x1 + L.L[1] * (x2 + L.L[2] * x3)));
+        }
+    int* dev = nullptr;
+    if (!tiles.empty()) {
+      HIP_TRY(c, hipMalloc(&dev, tiles.size() * sizeof(int)));
+      HIP_TRY(c, hipMemcpy(dev, tiles.data(), tiles.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    it = c->boundary_tiles.emplace(spb, std::make_pair(dev, static_cast<int>(tiles.size()))).first;
+  }
+  *list = it->second.first;
+  *n = it->second.second;
+  return BCG_OK;
+}
+
 // Profiling only: count the launches of each form of the stencil kernel ("stencil_form_k_hop4c" ...), so that tests
 // and tuning runs can tell which one a lattice shape gets.
 void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win) {
@@ -352,10 +380,15 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
       BCG_TRY(exchange_end(c));
     }
     {
+      bcg::HopTuning tb = c->hop_tune;
+      BCG_TRY(boundary_tile_list(c, 4 * (64 / m), &tb.boundary_list, &tb.boundary_n));
+      if (tb.boundary_n == 0) tb.boundary_list = nullptr;  // nothing to do: fall through to an empty class launch
       ProfScope ps(c, "hop_boundary");
-      nb2 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                 p ? p->d : nullptr, c0, gram ? c->partials + static_cast<size_t>(nb1) * m * m : c->partials,
-                                 gram, kFastBlocks, c->hop_tune, /*boundary*/ 2);
+      nb2 = tb.boundary_n == 0 ? 0
+                               : bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
+                                                      p ? p->d : nullptr, c0,
+                                                      gram ? c->partials + static_cast<size_t>(nb1) * m * m : c->partials, gram,
+                                                      kFastBlocks, tb, /*boundary*/ 2);
     }
     if (gram) *gram_blocks = nb1 + nb2;
     return check_launch(c, "hop_boundary");
@@ -711,6 +744,8 @@ int bcg_context_destroy(bcg_context* c) {
   }
   for (auto& kv : c->tmp_ring_buf)
     if (kv.second) (void)hipFree(kv.second);
+  for (auto& kv : c->boundary_tiles)
+    if (kv.second.first) (void)hipFree(kv.second.first);
   if (c->halo_send) (void)hipFree(c->halo_send);
   if (c->halo_recv) (void)hipFree(c->halo_recv);
   if (c->partials) (void)hipFree(c->partials);

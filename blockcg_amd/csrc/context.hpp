@@ -55,6 +55,7 @@ struct bcg_context {
   std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)
   int tmp_ring = 0;                      // capacity mode: `tmp` kept as a ring of this many x3 slices (0 = whole field)
   std::map<int, double2*> tmp_ring_buf;  // per width: the ring, tmp_ring * stride[3] * 3m complex
+  std::map<int, std::pair<int*, int>> boundary_tiles;  // per tile length: device list of the boundary tiles' first sites
   double2* halo_send = nullptr;
   double2* halo_recv = nullptr;
   size_t halo_bytes = 0;

@@ -621,6 +621,11 @@ struct HopWalk {
   // wait: after `sync_limit` ticks of the 100 MHz clock it stops pacing, so a block that is not resident cannot hang the rest).
   unsigned* sync;
   int sync_window, sync_stride, sync_limit;
+  // k_hop4 only: an explicit list of tiles (first site of each), dealt to the blocks round-robin, instead of the counter.
+  // Used for the boundary class of the split halo exchange: under the patch walk its tiles sit in a few columns, i.e. on
+  // a few blocks (all x2-edge columns belong to two XCD classes), and that launch is on the critical path.
+  const int* tile_list;
+  int list_n;
 };
 
 // Pacing counters are read with the same read-modify-write unit that increments them (an add of 0): the blocks of a
@@ -813,8 +818,30 @@ __global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, cons
                      (sp2 && (t.x2 == 0 || t.x2 == L2 - 1)) || (sp3 && (t.x3 == 0 || t.x3 == L3 - 1));
     return bnd == (CLS == 2);
   };
-  // advance (dg, left) to the next wanted tile; false when the block's sequence is exhausted
+  const int* const tlist = hw.tile_list;
+  // list mode: position in the list, dealt round-robin over all blocks (cutting the list into one contiguous part per XCD
+  // class instead was 2-5x slower in the two-rank rehearsal: the blocks of a class then sit on neighbouring addresses)
+  unsigned lpos = blockIdx.x;
+  auto geom_of_site = [&](int site0) -> TileGeom {
+    TileGeom t;
+    int q = site0 / L0;
+    t.x0b = site0 - q * L0;
+    const int q2 = q / L1;
+    t.x1 = q - q2 * L1;
+    t.x3 = q2 / L2;
+    t.x2 = q2 - t.x3 * L2;
+    t.site0 = site0;
+    t.edge = 0;
+    return t;
+  };
+  // advance to the next wanted tile; false when the block's sequence is exhausted
   auto next_tile = [&](TileGeom& t) -> bool {
+    if (tlist != nullptr) {
+      lpos += gridDim.x;
+      if (lpos >= static_cast<unsigned>(hw.list_n)) return false;
+      t = geom_of_site(tlist[lpos]);
+      return true;
+    }
     while (left > 0) {
       digits_add(dg, ds, r0, r1, r2, r3, r4, r5);
       --left;
@@ -825,7 +852,10 @@ __global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, cons
   };
   TileGeom g = geom_of<SPB>(dg, r0, hw.p1, hw.p2, L0, L1, L2, x3_lo);
   bool have = left > 0;
-  if (have) {
+  if (tlist != nullptr) {
+    have = lpos < static_cast<unsigned>(hw.list_n);
+    if (have) g = geom_of_site(tlist[lpos]);
+  } else if (have) {
     --left;  // `left` now counts the positions after the current one
     if (!wanted(g)) have = next_tile(g);
   }
@@ -1476,6 +1506,7 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
 struct HopPlan {
   bool valid = false;
   bool column = false;  // k_hop4c (column sweep, scalar row pointers) instead of k_hop4
+  bool list = false;    // k_hop4 over an explicit tile list (boundary class)
   int ntiles = 0, grid = 0;
   HopWalk hw{};
   HopWindow win{};
@@ -1493,8 +1524,16 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
   pl.ntiles = static_cast<int>(lat.V / lat.L[3] * win.x3_n / SPB);
   const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
                    lat.L[2] % p2 == 0 && pl.ntiles % 8 == 0 && max_blocks % 8 == 0 && pl.ntiles / 8 >= max_blocks / 8;
-  pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0};  // lexicographic = one patch
-  if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0};
+  pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, nullptr, 0};  // lexicographic = one patch
+  if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0, nullptr, 0};
+  if (cls == 2 && tune.boundary_list != nullptr) {  // the boundary class from its tile list, round-robin
+    pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, tune.boundary_list, tune.boundary_n};
+    pl.grid = tune.boundary_n < max_blocks ? tune.boundary_n : max_blocks;
+    pl.column = false;
+    pl.list = true;
+    pl.valid = true;
+    return pl;
+  }
   pl.grid = pl.ntiles < max_blocks ? pl.ntiles : max_blocks;
   if (pl.hw.xcd_split) pl.grid &= ~7;
   // column form of the walk: one block per tile of a patch slice, whole patches per XCD class
@@ -1524,6 +1563,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const HopWalk hw = pl.hw;
   const HopWindow win = pl.win;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
+  if (pl.list && grid == 0) return 0;  // no boundary tiles
+  const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
   if (pl.column) {
     if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
     const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
@@ -1564,8 +1605,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
 #define BCG_LAUNCH4_CLS(MM, MD, GR)                          \
   do {                                                       \
     if (win.ring > 0) BCG_LAUNCH4(MM, MD, GR, 0, true);      \
-    else if (cls == 1) BCG_LAUNCH4(MM, MD, GR, 1, false);    \
-    else if (cls == 2) BCG_LAUNCH4(MM, MD, GR, 2, false);    \
+    else if (cls_t == 1) BCG_LAUNCH4(MM, MD, GR, 1, false);  \
+    else if (cls_t == 2) BCG_LAUNCH4(MM, MD, GR, 2, false);  \
     else BCG_LAUNCH4(MM, MD, GR, 0, false);                  \
   } while (0)
   if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4_CLS(16, HOP_SHIFTED, true);

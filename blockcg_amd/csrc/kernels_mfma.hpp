@@ -38,6 +38,8 @@ struct HopTuning {
   int patch[3] = {0, 8, 8};      // patch extents in x0, x1, x2; 0 in x0 = one tile (16 sites at m = 16)
   int blocks = 512;              // persistent grid: 2 blocks per CU at the kernel's register budget
   HopSync sync;                  // pacing of the blocks of an XCD along x3
+  const int* boundary_list = nullptr;  // device list of the boundary tiles' first sites (set per launch by the context)
+  int boundary_n = 0;
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
   int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
                                  // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
