@@ -610,8 +610,8 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     return BCG_OK;
   }
   const CMat Rinv = bcg::upper_triangular_inverse(rho);
-  const int per = bcg::phaseC_max_shifts(m);
-  for (int s0 = 0, first = 1; first || s0 < n; s0 += per, first = 0) {
+  for (int s0 = 0, first = 1, per = 0; first || s0 < n; s0 += per, first = 0) {
+    per = bcg::phaseC_max_shifts(m, first != 0);
     const int ns = std::min(per, n - s0);
     std::vector<const CMat*> mats;
     mats.push_back(&Rinv);

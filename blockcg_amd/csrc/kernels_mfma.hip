@@ -349,9 +349,13 @@ __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restric
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nmat = 1 + 2 * nshift;
-  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k) * M * M, tid, 256);
+  // mats = [Rinv, A_0, B_0, A_1, B_1 ...]; Rinv takes an LDS slot only in the launch that applies it (at m = 32 a
+  // matrix is 16.6 KB: without it a launch that does not apply Rinv fits two shifts at two blocks per CU)
+  const int off = apply_rinv ? 0 : 1;
+  const int nmat = 1 + 2 * nshift - off;
+  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k + off) * M * M, tid, 256);
   __syncthreads();
+  const double* const smat = smem - off * MD;  // slot of mats[i] = smat + i * MD
   const int r = lane & 15, kq = lane >> 4;
   const int64_t ntiles = (rows + 15) / 16;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restric
       Acc<M> AX, AP;
       acc_from_tile<M>(AX, x);
       acc_from_tile<M>(AP, q);
-      rmul_acc2<M>(AX, smem + (1 + 2 * s) * MD, AP, smem + (2 + 2 * s) * MD, p, lane);
+      rmul_acc2<M>(AX, smat + (1 + 2 * s) * MD, AP, smat + (2 + 2 * s) * MD, p, lane);
       tile_from_acc<M>(x, AX);
       tile_store<M>(x, sp.X[s], row, kq, ok);
       tile_from_acc<M>(p, AP);
@@ -1429,7 +1433,7 @@ bool hop_can_split_tiles(int m, const LatticeDev& lat) {
   return hop_fast_width(m) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3];
 }
 bool mfma_rows_width(int m) { return m == 8 || m == 16 || m == 32; }  // right-multiply kernels (phase C, K5, K6)
-int phaseC_max_shifts(int m) { return (m == 16 || m == 8) ? 8 : (m == 32 ? 1 : 0); }
+int phaseC_max_shifts(int m, bool applies_rinv) { return (m == 16 || m == 8) ? 8 : (m == 32 ? (applies_rinv ? 1 : 2) : 0); }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
                   double2* partials, int max_blocks) {
@@ -1455,7 +1459,7 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
     sp.P[k] = P[k];
   }
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
-  const int nmat = 1 + 2 * nshift;
+  const int nmat = 1 + 2 * nshift - (apply_rinv ? 0 : 1);
   if (m == 8) {
     constexpr int M = 8;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;

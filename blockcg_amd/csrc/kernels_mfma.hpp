@@ -10,7 +10,7 @@ namespace bcg {
 
 bool mfma_rows_width(int m);    // widths whose right-multiplications (phase C, K5, K6) run on MFMA (8, 16, 32)
 bool hop_fast_width(int m);     // widths served by the LDS-staged stencil kernel (8, 16, 32)
-int phaseC_max_shifts(int m);   // shifts one phase-C launch can take (LDS budget)
+int phaseC_max_shifts(int m, bool applies_rinv);  // shifts one phase-C launch can take (LDS budget; Rinv takes a slot)
 
 // Phase B: Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
