@@ -41,31 +41,13 @@ __device__ __forceinline__ double2 ld_nt(const double2* p) {
   const dv2 v = __builtin_nontemporal_load(reinterpret_cast<const dv2*>(p));
   return make_double2(v.x, v.y);
 }
-// link loads of the stencil: streamed (each link is needed by one tile, its backward copy by one more), so they are
-// marked non-temporal to leave the L2 to the field slices that are re-used (BCG_HOP4_U_NT=0: plain loads)
-#ifndef BCG_HOP4_U_NT
-#define BCG_HOP4_U_NT 0
-#endif
-__device__ __forceinline__ dv2 ld_link(const dv2* p) {
-#if BCG_HOP4_U_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-#ifndef BCG_HOP4_ST_SC1
-#define BCG_HOP4_ST_SC1 0
-#endif
+// link loads of the stencil (non-temporal loads were tried here: 13 % fewer L2 misses, no time gained)
+__device__ __forceinline__ dv2 ld_link(const dv2* p) { return *p; }
 __device__ __forceinline__ void st_nt(double2* p, double2 v) {
   dv2 w;
   w.x = v.x;
   w.y = v.y;
-#if BCG_HOP4_ST_SC1
-  // write-through store that does not keep the line in the L2 (sc1), for output that is not read again by this kernel
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(reinterpret_cast<dv2*>(p)), "v"(w) : "memory");
-#else
   __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(p));
-#endif
 }
 
 // ---- coefficient matrices in LDS ------------------------------------------------------------------
@@ -721,14 +703,8 @@ __device__ __forceinline__ void fetch_back(int mu, int xm, int Lm, int Sm, int s
 // of 2 waves per SIMD in __launch_bounds__ costs 1.5 ms on both, so: CARRY = GRAM, plain __launch_bounds__(256).
 // CLS selects the tiles a launch processes: 0 all, 1 interior only (no site of the tile reads a ghost), 2 boundary only.
 // Interior and boundary launches bracket the halo exchange so that it overlaps the interior arithmetic.
-#ifndef BCG_HOP4_ATTR
-#define BCG_HOP4_ATTR
-#endif
-#ifndef BCG_HOP4_SCHED
-#define BCG_HOP4_SCHED 0
-#endif
 template <int M, int MODE, bool GRAM, bool NT, int CLS, bool RING>
-__global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, const double2* __restrict__ U,
+__global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __restrict__ U,
                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                               const double2* __restrict__ ghost, double2* __restrict__ out,
                                               const double2* __restrict__ p, double c0,
@@ -959,28 +935,6 @@ __global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, cons
     const bool carry_b3 = CARRY_B3 && cur.x3 > 0 && fsite_m2 == cur.site0 - S3;
     const int fsite_now = (cur.x3 + 1 < L3) ? cur.site0 + S3 : (sp3 ? -1 : cur.site0 - (L3 - 1) * S3);
     double2 f[4][3], bk[4][3];
-#ifndef BCG_HOP4_HALO_NT
-#define BCG_HOP4_HALO_NT 0
-#endif
-#if BCG_HOP4_HALO_NT
-    // x1/x2 neighbours outside the patch are needed once per sweep: stream them past the L2 (uniform branches)
-#define BCG_LD3(DST, SRC, COND)                                                  \
-  if (COND) {                                                                    \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) DST[k] = ld_nt(SRC + k * M + j); \
-  } else {                                                                       \
-    _Pragma("unroll") for (int k = 0; k < 3; ++k) DST[k] = SRC[k * M + j];       \
-  }
-    BCG_LD3(f[1], nf1, cur.edge & 1)
-    BCG_LD3(bk[1], nb1, cur.edge & 2)
-    BCG_LD3(f[2], nf2, cur.edge & 4)
-    BCG_LD3(bk[2], nb2, cur.edge & 8)
-#undef BCG_LD3
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
-      f[3][k] = nf3[k * M + j];
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       f[0][k] = nf0[k * M + j]; bk[0][k] = nb0[k * M + j];
@@ -988,7 +942,6 @@ __global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, cons
       f[2][k] = nf2[k * M + j]; bk[2][k] = nb2[k * M + j];
       f[3][k] = nf3[k * M + j];
     }
-#endif
     if (carry_b3) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) bk[3][k] = make_double2(h2[k].x, h2[k].y);
@@ -1013,9 +966,6 @@ __global__ void __launch_bounds__(256) BCG_HOP4_ATTR k_hop4(LatticeDev lat, cons
 #pragma unroll
       for (int r = 0; r < 3; ++r) pv[r] = NT ? ld_nt(p + o0 + r * M) : p[o0 + r * M];
     }
-#if BCG_HOP4_SCHED
-    __builtin_amdgcn_sched_barrier(0);  // keep every neighbour load ahead of the arithmetic (memory-level parallelism)
-#endif
     double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
     const int par1 = x0 + og0, par2 = par1 + cur.x1 + og1, par3 = par2 + cur.x2 + og2;
 #pragma unroll
@@ -1237,9 +1187,6 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
         }
       }
       __syncthreads();
-#ifndef BCG_HOP4C_LINKPOS
-#define BCG_HOP4C_LINKPOS 0
-#endif
 #define BCG_PREFETCH_LINKS                                                                        \
   {                                                                                               \
     int nx = x3 + 1; /* the next tile of this launch in the column: its links are parked first thing there */ \
@@ -1251,9 +1198,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
       links_for = nx;                                                                             \
     }                                                                                             \
   }
-#if BCG_HOP4C_LINKPOS == 0
       BCG_PREFETCH_LINKS
-#endif
       const double2* Lf = Ls + stage * STAGE;
       const double2* Lb = Lf + NF;
       stage ^= 1;
@@ -1288,13 +1233,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
     f[MU][k] = ld_sv(qf[MU], (MU) == 0 ? voff_p : voff, k * M * 16);                       \
     bk[MU][k] = ld_sv(qb[MU], (MU) == 0 ? voff_m : voff, k * M * 16);                      \
   }
-#ifndef BCG_HOP4C_AHEAD
-#define BCG_HOP4C_AHEAD 1
-#endif
       BCG_LOAD_DIR(0)
-#if BCG_HOP4C_AHEAD == 2
-      BCG_LOAD_DIR(1)
-#endif
       if (gh0p || gh0m) {  // direction 0 divided over ranks: the edge site of an end-of-row tile reads the ghost face
         const int64_t f0 = x1 + L1 * (x2 + L2 * x3);
         if (gh0p && sl == SPB - 1) {
@@ -1322,24 +1261,9 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
-#if BCG_HOP4C_AHEAD == 2
-        if (mu == 0) { BCG_LOAD_DIR(2) }
-        if (mu == 1) {
-#else
-        if (mu == 0) {
-          BCG_LOAD_DIR(1)
-#if BCG_HOP4C_LINKPOS == 1
-          BCG_PREFETCH_LINKS
-#endif
-        }
-        if (mu == 1) {
-          BCG_LOAD_DIR(2)
-#if BCG_HOP4C_LINKPOS == 2
-          BCG_PREFETCH_LINKS
-#endif
-        }
+        if (mu == 0) { BCG_LOAD_DIR(1) }
+        if (mu == 1) { BCG_LOAD_DIR(2) }
         if (mu == 2) {
-#endif
           // Vector memory returns in issue order, so what misses the L2 goes last: the new slice (+x3), then p.
           // (The next tile's links also miss, but issued this late they are not back when that tile parks them: 15.4 ms.)
           BCG_LOAD_DIR(3)
