@@ -356,7 +356,11 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   const int m = in->m;
   if (gram_blocks) *gram_blocks = 0;
   const bool fast = fast_hop(c, m);
-  const bool gram = fast && gram_blocks && m == 16 && mode == bcg::HOP_SHIFTED;
+  // fused Gram product: m = 16 in every form of the specialised stencil; m = 8 in the column-sweep kernel, one launch
+  const bool split_path = fast && bcg::hop_can_split_tiles(m, c->lat) && can_overlap(c);
+  const bool gram = fast && gram_blocks && mode == bcg::HOP_SHIFTED &&
+                    (m == 16 || (m == 8 && !split_path &&
+                                 bcg::hop_kernel_form(m, c->lat, kFastBlocks, c->hop_tune, 0, bcg::HopWindow()) == 2));
   const char* name = gram ? "hop_shifted_gram" : (mode == bcg::HOP_PLAIN ? "hop" : "hop_shifted");
   if (fast) BCG_TRY(ensure_scratch(c));
   // BCG_FORCE_TILE_CLASSES=1 (tuning aid): take the two-launch path on an undivided lattice too, where every tile is

@@ -263,6 +263,36 @@ __device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* re
   }
 }
 
+// m = 8 on the 16x16 MFMA tile.  With lane = (row pair k = l>>4, row parity s = (l>>3)&1, column c = l&7) holding the
+// element (row 2k+s, column c) of both operands, gram_step<16> accumulates C[(s,i)][(s',j)] = sum_k conj(a(2k+s,i)) b(2k+s',j):
+// the two diagonal blocks s = s' are Gram contributions (even and odd rows), the off-diagonal ones are discarded.  So
+// the whole m = 16 machinery applies unchanged and only this final store differs: G(i,j) = C[i][j] + C[8+i][8+j].
+template <int NW>
+__device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, double* red, double2* __restrict__ partials, int tid) {
+  constexpr int FR = 8;  // doubles per lane
+  const int wave = tid >> 6, lane = tid & 63;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[((wave * FR) + r) * 64 + lane] = G.re[0][r];
+    red[((wave * FR) + 4 + r) * 64 + lane] = G.im[0][r];
+  }
+  __syncthreads();
+  // fragment element (r, l): i16 = (l>>4) + 4r, j16 = l&15.  Block (0,0): r < 2, (l&15) < 8; its partner in block (1,1): (r+2, l+8)
+  for (int e = tid; e < 4 * 64; e += NW * 64) {
+    const int l = e & 63, r = e >> 6;
+    if (r >= 2 || (l & 15) >= 8) continue;
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      sr += red[((w * FR) + r) * 64 + l] + red[((w * FR) + r + 2) * 64 + l + 8];
+      si += red[((w * FR) + 4 + r) * 64 + l] + red[((w * FR) + 4 + r + 2) * 64 + l + 8];
+    }
+    const int i = (l >> 4) + 4 * r, j = l & 7;
+    partials[static_cast<int64_t>(blockIdx.x) * 64 + j * 8 + i] = make_double2(sr, si);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Phase B:  Q -= T*alpha  (matrix passed as -alpha),  accumulate Q^dagger Q of the NEW Q.
 // ---------------------------------------------------------------------------------------------------
@@ -1034,7 +1064,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
                                            const double2* __restrict__ ghost, double2* __restrict__ out,
                                            const double2* __restrict__ p, double c0, double2* __restrict__ partials,
                                            const HopWalk& hw, const HopWindow& win) {
-  static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
+  static_assert(!GRAM || M == 16 || M == 8, "fused Gram accumulation: lane&15 = rhs index (m = 16) or (site parity, rhs) (m = 8)");
   constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
   constexpr int SPW = 64 / M;
@@ -1313,7 +1343,10 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
     }
   }
 #undef BCG_FETCH_LINKS
-  if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
+  if (GRAM) {
+    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
+    else gram_block_store<16, NW>(G, smem, partials, tid);
+  }
 }
 
 // Entry points.  The interior-class fused-Gram variant (and those of m = 8) need 260-280 VGPRs as scheduled by default,
@@ -1348,9 +1381,68 @@ void allow_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
+// Gram product at m = 8 (see gram_block_store_fold8): 8 rows of 8 columns per MFMA step, 16 B per lane, 1 KB per wave.
+__global__ void __launch_bounds__(256) k_gram_mfma8(int64_t rows, const double2* __restrict__ a, const double2* __restrict__ b,
+                                                    double2* __restrict__ partials) {
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  GramAcc<16> G;
+  gram_zero(G);
+  const int64_t nsteps = (rows + 7) / 8;
+  for (int64_t st = static_cast<int64_t>(blockIdx.x) * NW + wave; st < nsteps; st += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = st * 8 + (lane >> 3);
+    const bool ok = row < rows;
+    const double2 av = ok ? a[row * 8 + (lane & 7)] : make_double2(0.0, 0.0);
+    const double2 bv = ok ? b[row * 8 + (lane & 7)] : make_double2(0.0, 0.0);
+    gram_step<16>(G, &av, &bv);
+  }
+  gram_block_store_fold8<NW>(G, smem, partials, tid);
+}
+
+// Phase B at m = 8: Q += T * negalpha through the m = 8 product tile, then the new 16 x 8 tile is re-read from a per-wave
+// LDS buffer in (row, column) ownership for the folded Gram product.
+__global__ void __launch_bounds__(256) k_phaseB8(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
+                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials) {
+  constexpr int M = 8, NW = 4;
+  constexpr int TLD = M * 2 + 2;  // doubles per transposition row
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ml = smem;
+  double* scratch = smem + ((MatLds<M>::DOUBLES + 1) & ~1);  // max(NW*16*TLD, NW*8*64) doubles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(Ml, negalpha, tid, 256);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  double* tw = scratch + wave * 16 * TLD;
+  GramAcc<16> G;
+  gram_zero(G);
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = row < rows;
+    Tile<M> t, q;
+    tile_load<M>(t, T, row, kq, ok);
+    tile_load<M>(q, Q, row, kq, ok);
+    Acc<M> A;
+    acc_from_tile<M>(A, q);
+    rmul_acc<M>(A, t, Ml, lane);
+    tile_from_acc<M>(q, A);
+    tile_store<M>(q, Q, row, kq, ok);
+#pragma unroll
+    for (int sx = 0; sx < M / 4; ++sx) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * sx + kq)) = ok ? q.v[sx] : make_double2(0.0, 0.0);
+    // same wave wrote and reads (LDS operations of one wave are in order): rows 8g .. 8g+7, one per 8 lanes
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const double2 av = *reinterpret_cast<const double2*>(tw + (8 * g + (lane >> 3)) * TLD + 2 * (lane & 7));
+      gram_step<16>(G, &av, &av);
+    }
+  }
+  gram_block_store_fold8<NW>(G, scratch, partials, tid);
+}
+
 }  // namespace
 
-bool mfma_width(int m) { return m == 16 || m == 32; }  // declared in kernels.hpp
+bool mfma_width(int m) { return m == 8 || m == 16 || m == 32; }  // declared in kernels.hpp
 bool hop_fast_width(int m) { return m == 8 || m == 16 || m == 32; }
 bool hop_can_split_tiles(int m, const LatticeDev& lat) {
   const int spb = 4 * (64 / m);
@@ -1362,7 +1454,10 @@ int phaseC_max_shifts(int m, bool applies_rinv) { return (m == 16 || m == 8) ? 8
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
                   double2* partials, int max_blocks) {
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
-  if (m == 16) {
+  if (m == 8) {
+    const size_t lds = sizeof(double) * (((MatLds<8>::DOUBLES + 1) & ~1) + 4 * 8 * 64);  // RED 2048 >= TRN 4*16*18
+    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+  } else if (m == 16) {
     constexpr int M = 16;
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
     hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
@@ -1419,7 +1514,10 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
                      int max_blocks) {
   const int grid = grid_tiles((rows + 3) / 4, 4 * 16, max_blocks);
-  if (m == 16) {
+  if (m == 8) {
+    const size_t lds = sizeof(double) * 4 * 8 * 64;
+    hipLaunchKernelGGL(k_gram_mfma8, dim3(grid), dim3(256), lds, s, rows, a, b, partials);
+  } else if (m == 16) {
     const size_t lds = sizeof(double) * 4 * 8 * 64;
     hipLaunchKernelGGL((k_gram_mfma<16>), dim3(grid), dim3(256), lds, s, rows, a, b, partials);
   } else {
@@ -1515,6 +1613,7 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
     else BCG_LAUNCH4C(MM, MD, GR, 0, false);                \
   } while (0)
     if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4C_R(16, HOP_SHIFTED, true);
+    else if (gram && M == 8 && mode == HOP_SHIFTED) BCG_LAUNCH4C_R(8, HOP_SHIFTED, true);
     else if (mode == HOP_PLAIN) BCG_LAUNCH4C_R(M, HOP_PLAIN, false);
     else BCG_LAUNCH4C_R(M, HOP_SHIFTED, false);
 #undef BCG_LAUNCH4C_R
