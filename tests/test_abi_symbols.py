@@ -37,6 +37,17 @@ def test_bindings_cover_the_header():
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 with no C++ (or torch) types in any signature."""
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "blockcg_hip.h"\n'
+                   "int probe(void) { bcg_context* c = 0; size_t n = 0; bcg_comm k; (void)k;\n"
+                   "  return bcg_sbcgrq_device_bytes(c, 16, 4, 1, &n) + bcg_capacity_mode(c, 0); }\n")
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                          "-c", str(src), "-o", str(tmp_path / "use_header.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def test_library_contains_gfx950_code_object():
     import blockcg_amd
     data = open(blockcg_amd.LIB_PATH, "rb").read()
