@@ -365,7 +365,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   if (fast) BCG_TRY(ensure_scratch(c));
   // BCG_FORCE_TILE_CLASSES=1 (tuning aid): take the two-launch path on an undivided lattice too, where every tile is
   // an interior one, to time the interior-class kernel on one GPU
-  static const bool force_classes = std::getenv("BCG_FORCE_TILE_CLASSES") && std::atoi(std::getenv("BCG_FORCE_TILE_CLASSES")) != 0;
+  const bool force_classes = c->force_tile_classes;
   if (fast && bcg::hop_can_split_tiles(m, c->lat) && (can_overlap(c) || (force_classes && !c->distributed))) {
     // pack -> post the exchange -> interior tiles (no ghost reads) -> wait for the exchange -> boundary tiles
     if (c->distributed) BCG_TRY(halo_field(c, in, /*split=*/true));
@@ -722,6 +722,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_SYNC")) c->hop_tune.sync.window = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_SYNC_LIMIT")) c->hop_tune.sync.limit_ticks = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);
   if (stream) {

@@ -48,6 +48,7 @@ struct bcg_context {
   bcg_comm comm{};
   bool have_comm = false;
   bool force_generic = false;
+  bool force_tile_classes = false;  // tuning/test aid: interior + boundary stencil launches on an undivided lattice too
   int row_blocks_B = 1024, row_blocks_C = 1024;  // persistent grids of the fused row kernels (phase B, phase C)
   bcg::HopTuning hop_tune;  // specialised stencil: tile walk, patch shape, grid, streaming hints
 

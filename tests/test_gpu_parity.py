@@ -196,6 +196,35 @@ def test_config2_64c4_m16_4shifts_solves_to_tolerance(bc):
         assert np.sqrt(r2 / b2).max() < 2 * eps, s
 
 
+def test_full_size_capacity_mode_and_tile_classes_agree_with_default(bc, monkeypatch):
+    """At BASELINE's full single-GPU size (64^4, m=16, 4 shifts) the three ways the stencil can be launched -- one
+    launch, capacity mode (ring of x3 slices) and the interior/boundary classes of the split exchange (forced on an
+    undivided lattice) -- must give the same iteration count and solutions (size-independent property: the operator
+    is the same linear map)."""
+    dims, m, mass, eps = [64, 64, 64, 64], 16, 0.5, 1e-8
+    shifts = [0.0, 1e-2]
+    got = {}
+    for mode in ("default", "capacity", "classes"):
+        monkeypatch.setenv("BCG_FORCE_TILE_CLASSES", "1" if mode == "classes" else "0")
+        ctx = bc.Context(dims)
+        if mode == "capacity":
+            ctx.capacity_mode(8)
+        D = bc.dirac_op(ctx, mass, seed=31)
+        B = bc.block_fermion_field(ctx, m).setRandom(seed=32)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        it = bc.SBCGrQ(X, B, D, shifts, eps, eps, max_iterations=200)
+        assert 0 < it < 200
+        res = bc.true_residuals(X, B, D, shifts)
+        assert res.max() < 2 * eps
+        # a cheap fingerprint of the solutions: their Gram matrices with the source
+        got[mode] = (it, [B.hermitian_dot(x) for x in X])
+        del X, B, D, ctx
+    for mode in ("capacity", "classes"):
+        assert got[mode][0] == got["default"][0]
+        for a, b in zip(got[mode][1], got["default"][1]):
+            assert rel_err(a, b) < 1e-9
+
+
 def test_error_behaviour(bc):
     ctx = bc.Context([16])
     D = bc.dirac_op(ctx, 0.5, seed=1)
