@@ -46,9 +46,10 @@ def kernel_bytes(name, V, m, S, ndim):
     return V * table[name] if name in table else None
 
 
-def cpu_baseline(m, S, shifts, mass, budget_iters=8):
+def cpu_baseline(m, S, shifts, mass, budget_iters=32):
     """Time the reference's own SBCGrQ (oracle/_ref, built from /root/reference in the build container)
-    or, if that is absent, this repository's CPU restatement, on one host core, at V = 16^4."""
+    or, if that is absent, this repository's CPU restatement, on one host core, at V = 16^4: a bounded sample of the
+    same workload (32 fixed iterations, about 13 s)."""
     import numpy as np
     import oracle
     dims = [16, 16, 16, 16]
