@@ -1620,7 +1620,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
 #undef BCG_LAUNCH4C
     return grid;
   }
-  const size_t lds_u = sizeof(double2) * 3 * ((SPB + 1) * 36 + 3 * SPB * 9);  // room for the 3-stage (carry) variant
+  // link images: three for the fused-Gram variant (x3 carry reads the previous one), two otherwise
+  const size_t lds_u = sizeof(double2) * ((gram && M == 16 && mode == HOP_SHIFTED) ? 3 : 2) * ((SPB + 1) * 36 + 3 * SPB * 9);
   const size_t lds = lds_u > lds_g ? lds_u : lds_g;
   // the streaming (non-temporal) form is the only one instantiated
 #define BCG_LAUNCH4(MM, MD, GR, CL, RG)                                                                                   \
