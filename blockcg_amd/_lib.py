@@ -54,6 +54,7 @@ SIGNATURES = {
     "bcg_field_width": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_upload": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
     "bcg_field_download": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
+    "bcg_field_download_sites": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), c_dbl_p]),
     "bcg_field_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "bcg_field_set_zero": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_fill_random": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),

@@ -153,6 +153,14 @@ class block_fermion_field:
         self.ctx.check(self.ctx.lib.bcg_field_download(self.h, _dp(a)))
         return a
 
+    def download_sites(self, sites):
+        """Tiles of chosen local sites, [len(sites), N_rhs, 3] (operator[] read access, inc/fields.hpp:37-38)."""
+        sites = np.ascontiguousarray(sites, dtype=np.int64)
+        a = np.empty((len(sites), self.N_rhs, 3), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.bcg_field_download_sites(self.h, len(sites),
+                                                             sites.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(a)))
+        return a
+
     def copy(self):
         f = block_fermion_field(self.ctx, self.N_rhs)
         self.ctx.check(self.ctx.lib.bcg_field_copy(f.h, self.h))

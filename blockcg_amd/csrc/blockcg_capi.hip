@@ -958,6 +958,26 @@ int bcg_field_download(const bcg_field* f, double* host) {
   return BCG_OK;
 }
 
+int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites, double* host) {
+  if (!f || n < 0 || (n > 0 && (!sites || !host))) return BCG_ERR_INVALID;
+  bcg_context* c = f->ctx;
+  for (int64_t k = 0; k < n; ++k)
+    if (sites[k] < 0 || sites[k] >= c->lat.V) BCG_FAIL(c, BCG_ERR_INVALID, "bcg_field_download_sites: site out of range");
+  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
+  const int64_t chunk = 4096;
+  BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
+  for (int64_t k0 = 0; k0 < n; k0 += chunk) {
+    const int64_t nk = std::min<int64_t>(chunk, n - k0);
+    for (int64_t k = 0; k < nk; ++k)  // one tile each: the layout conversion of bcg_field_download on a single site
+      bcg::launch_dev_to_host(c->stream, f->m, f->d + sites[k0 + k] * 3 * f->m, c->staging + k * 3 * f->m, 1);
+    BCG_TRY(check_launch(c, "dev_to_host"));
+    HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char*>(host) + k0 * site_bytes, c->staging, nk * site_bytes,
+                              hipMemcpyDeviceToHost, c->stream));
+    BCG_TRY(stream_sync(c));
+  }
+  return BCG_OK;
+}
+
 int bcg_field_copy(bcg_field* dst, const bcg_field* src) {
   if (!same_shape(dst, src)) return BCG_ERR_INVALID;
   bcg_context* c = dst->ctx;

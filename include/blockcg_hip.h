@@ -126,6 +126,9 @@ int bcg_field_destroy(bcg_field* f);
 int bcg_field_width(const bcg_field* f);
 int bcg_field_upload(bcg_field* f, const double* host);                 /* host -> device, layout conversion */
 int bcg_field_download(const bcg_field* f, double* host);               /* device -> host */
+/* operator[](int) :37-38 read access without moving the whole field: the tiles of n chosen LOCAL sites,
+ * host[k] = f[sites[k]] in the host layout ([rhs][colour], 48*m bytes each).  Sites out of range: BCG_ERR_INVALID. */
+int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites, double* host);
 int bcg_field_copy(bcg_field* dst, const bcg_field* src);               /* copy-construct / assignment */
 int bcg_field_set_zero(bcg_field* f);                                   /* setZero :57-61 */
 /* i.i.d. uniform [-1,1) per real component from the counter-based generator shared with the

@@ -104,6 +104,45 @@ class Oracle:
         self.lib.orc_fill_gauge(nd, _dims(dims), seed, _dp(out))
         return out
 
+    # --- host threads for the site loops (1 = the reference's sequential summation order) ---
+    def set_threads(self, n):
+        return self.lib.orc_set_threads(int(n))
+
+    # --- sampled evaluator: (D psi)(x), (A psi)(x) at chosen global sites of a generated lattice ---
+    def hop_sampled(self, m, dims, seed_U, seed_psi, sites):
+        sites = np.ascontiguousarray(sites, dtype=np.int64)
+        out = np.empty((len(sites), m, 3), dtype=np.complex128)
+        self.lib.orc_hop_sampled.argtypes = [ctypes.c_int, ctypes.c_int, _c_int_p, ctypes.c_uint64, ctypes.c_uint64,
+                                             ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _c_dbl_p]
+        self._chk(self.lib.orc_hop_sampled(m, len(dims), _dims(dims), seed_U, seed_psi, len(sites),
+                                           sites.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(out)))
+        return out
+
+    def apply_sampled(self, m, dims, seed_U, seed_psi, mass, sites):
+        sites = np.ascontiguousarray(sites, dtype=np.int64)
+        out = np.empty((len(sites), m, 3), dtype=np.complex128)
+        self.lib.orc_apply_sampled.argtypes = [ctypes.c_int, ctypes.c_int, _c_int_p, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_double, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), _c_dbl_p]
+        self._chk(self.lib.orc_apply_sampled(m, len(dims), _dims(dims), seed_U, seed_psi, mass, len(sites),
+                                             sites.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(out)))
+        return out
+
+    def sbcgrq_generated(self, m, dims, seed_U, seed_B, mass, sigma, iterations):
+        """SBCGrQ trace of the first `iterations` iterations on generated inputs (no lattice-sized numpy arrays)."""
+        S = len(sigma)
+        sig = np.ascontiguousarray(sigma, dtype=np.float64)
+        tr_m = np.zeros((iterations, 3 + 2 * S, m, m), dtype=np.complex128)
+        tr_r = np.zeros((iterations, 1 + S), dtype=np.float64)
+        it = ctypes.c_int(0)
+        self.lib.orc_sbcgrq_generated.argtypes = [ctypes.c_int, ctypes.c_int, _c_int_p, ctypes.c_uint64, ctypes.c_uint64,
+                                                  ctypes.c_double, ctypes.c_int, _c_dbl_p, ctypes.c_int, _c_dbl_p, _c_dbl_p,
+                                                  _c_int_p]
+        self._chk(self.lib.orc_sbcgrq_generated(m, len(dims), _dims(dims), seed_U, seed_B, mass, S, _dp(sig), iterations,
+                                                _dp(tr_m), _dp(tr_r), ctypes.byref(it)))
+        mats = np.ascontiguousarray(np.swapaxes(tr_m, -1, -2))
+        return dict(iterations=it.value, alpha=mats[:, 0], rho=mats[:, 1], delta=mats[:, 2], alpha_s=mats[:, 3:3 + S],
+                    beta_s=mats[:, 3 + S:3 + 2 * S], residual=tr_r[:, 0], residual_shift=tr_r[:, 1:])
+
     # --- K1 + op ---
     def hop(self, U, dims, x):
         x = _f(x)

@@ -72,6 +72,72 @@ int orc_fill_gauge(int ndim, const int* dims, uint64_t seed, double* out) {
   return 0;
 }
 
+// Host threads for the site loops (oracle::threads()); 1 = the reference's sequential order.
+int orc_set_threads(int n) {
+  threads() = n < 1 ? 1 : n;
+  return threads();
+}
+
+// Sampled evaluator (oracle.hpp): out[k] = (D psi)(sites[k]) resp. (A psi)(sites[k]), [nsites][m][3] complex, with U and
+// psi from the counter-based generator (seed_U, seed_psi); nothing of size V is allocated.
+int orc_hop_sampled(int m, int ndim, const int* dims, uint64_t seed_U, uint64_t seed_psi, int64_t nsites,
+                    const int64_t* sites, double* out) {
+  const Lattice lat(ndim, dims);
+  ORC_DISPATCH(m, {
+    BLOCKCG_ORACLE_PARALLEL_FOR
+    for (int64_t k = 0; k < nsites; ++k)
+      hop_sampled_site<M>(reinterpret_cast<cplx*>(out) + k * M * NC, lat, seed_U, seed_psi, sites[k]);
+  });
+  return 0;
+}
+int orc_apply_sampled(int m, int ndim, const int* dims, uint64_t seed_U, uint64_t seed_psi, double mass, int64_t nsites,
+                      const int64_t* sites, double* out) {
+  const Lattice lat(ndim, dims);
+  ORC_DISPATCH(m, {
+    BLOCKCG_ORACLE_PARALLEL_FOR
+    for (int64_t k = 0; k < nsites; ++k)
+      apply_sampled_site<M>(reinterpret_cast<cplx*>(out) + k * M * NC, lat, seed_U, seed_psi, mass, sites[k]);
+  });
+  return 0;
+}
+
+// SBCGrQ on generated inputs (gauge seed_U, source seed_B) without passing lattice-sized arrays through the caller: the
+// m x m coefficients of the first `max_iterations` iterations at sizes such as 64^4 (with orc_set_threads > 1).
+// Trace layout as orc_sbcgrq.  X is not returned.
+int orc_sbcgrq_generated(int m, int ndim, const int* dims, uint64_t seed_U, uint64_t seed_B, double mass, int nshift,
+                         const double* sigma, int max_iterations, double* tr_mats, double* tr_res, int* iters_out) {
+  Gauge g{Lattice(ndim, dims)};
+  g.fill_random(seed_U);
+  const int64_t V = g.lat.V;
+  std::vector<double> sig(sigma, sigma + nshift);
+  ORC_DISPATCH(m, {
+    Field<M> fB(V);
+    fB.fill_random(seed_B);
+    std::vector<Field<M>> X(nshift, Field<M>(V));
+    std::vector<IterTrace> trace;
+    const int it = SBCGrQ<M>(X, fB, g, mass, sig, 0.0, 0.0, max_iterations, &trace, max_iterations);
+    if (iters_out) *iters_out = it;
+    const size_t mm2 = static_cast<size_t>(m) * m * 2;
+    for (size_t k = 0; k < trace.size(); ++k) {
+      double* p = tr_mats + k * (3 + 2 * nshift) * mm2;
+      store_mat(trace[k].alpha, p);
+      store_mat(trace[k].rho, p + mm2);
+      store_mat(trace[k].delta, p + 2 * mm2);
+      for (int s = 0; s < nshift; ++s) {
+        store_mat(trace[k].alpha_s[s], p + (3 + s) * mm2);
+        store_mat(trace[k].beta_s[s], p + (3 + nshift + s) * mm2);
+      }
+      if (tr_res) {
+        double* q = tr_res + k * (1 + nshift);
+        q[0] = trace[k].residual;
+        for (int s = 0; s < nshift; ++s) q[1 + s] = trace[k].residual_shift[s];
+      }
+    }
+  });
+  return 0;
+}
+
+
 int orc_hop(int m, int ndim, const int* dims, const double* U, const double* in, double* out) {
   Gauge g = load_gauge(ndim, dims, U);
   ORC_DISPATCH(m, {
