@@ -101,11 +101,22 @@ _lib = None
 
 
 def build(verbose=False):
-    """Compile libblockcg_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
-    if not verbose:
-        cmd.append("-s")
-    subprocess.run(cmd, check=True)
+    """Compile libblockcg_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    Serialised across processes with a file lock: under `torch.distributed.run --nproc-per-node N` on a fresh checkout
+    every rank would otherwise run make at once and write the same objects.  The Makefile links to a temporary name and
+    renames, so a reader never maps a half-written library."""
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]  # a no-op when another rank has just built it
+            if not verbose:
+                cmd.append("-s")
+            subprocess.run(cmd, check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def load():

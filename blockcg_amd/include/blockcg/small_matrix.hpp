@@ -25,6 +25,81 @@ inline cplx eigen_random_complex() {
   return cplx(re, im);
 }
 
+// Coefficient-wise real array / real vector of fixed length: what Eigen's .real(), .array(), .rowwise().norm() yield in
+// the reference's residual expressions (benchmark.cpp:100-101, inc/block_solvers.hpp:20,42,62,83,130,155,170-172):
+//   (r2.diagonal().real().array() / b2.diagonal().array().real()).maxCoeff()
+//   (delta.rowwise().norm().array() / b_norm).maxCoeff(),   r2.diagonal().real().array().sqrt()
+template <int N>
+struct rarray {
+  double v[N];
+  rarray() {
+    for (int i = 0; i < N; ++i) v[i] = 0.0;
+  }
+  double& operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+  static constexpr int size() { return N; }
+  const rarray& array() const { return *this; }
+  const rarray& matrix() const { return *this; }
+  const rarray& real() const { return *this; }
+  const rarray& eval() const { return *this; }
+  rarray sqrt() const {
+    rarray r;
+    for (int i = 0; i < N; ++i) r.v[i] = std::sqrt(v[i]);
+    return r;
+  }
+  double maxCoeff() const {
+    double m = v[0];
+    for (int i = 1; i < N; ++i) m = v[i] > m ? v[i] : m;
+    return m;
+  }
+  double minCoeff() const {
+    double m = v[0];
+    for (int i = 1; i < N; ++i) m = v[i] < m ? v[i] : m;
+    return m;
+  }
+  double sum() const {
+    double s = 0.0;
+    for (int i = 0; i < N; ++i) s += v[i];
+    return s;
+  }
+};
+template <int N>
+inline rarray<N> operator/(const rarray<N>& a, const rarray<N>& b) {
+  rarray<N> r;
+  for (int i = 0; i < N; ++i) r.v[i] = a.v[i] / b.v[i];
+  return r;
+}
+template <int N>
+inline rarray<N> operator*(const rarray<N>& a, const rarray<N>& b) {
+  rarray<N> r;
+  for (int i = 0; i < N; ++i) r.v[i] = a.v[i] * b.v[i];
+  return r;
+}
+template <int N>
+inline rarray<N> sqrt(const rarray<N>& a) { return a.sqrt(); }
+
+// complex counterpart: diagonal() of a matrix
+template <int N>
+struct carray {
+  cplx v[N];
+  cplx& operator()(int i) { return v[i]; }
+  const cplx& operator()(int i) const { return v[i]; }
+  const carray& array() const { return *this; }
+  const carray& matrix() const { return *this; }
+  rarray<N> real() const {
+    rarray<N> r;
+    for (int i = 0; i < N; ++i) r.v[i] = v[i].real();
+    return r;
+  }
+  rarray<N> imag() const {
+    rarray<N> r;
+    for (int i = 0; i < N; ++i) r.v[i] = v[i].imag();
+    return r;
+  }
+};
+
 template <int Rows, int Cols>
 class cmatrix {
  public:
@@ -78,6 +153,20 @@ class cmatrix {
     for (int k = 0; k < Rows * Cols; ++k) r.v[k] = -v[k];
     return r;
   }
+  carray<(Rows < Cols ? Rows : Cols)> diagonal() const {
+    carray<(Rows < Cols ? Rows : Cols)> d;
+    for (int i = 0; i < (Rows < Cols ? Rows : Cols); ++i) d.v[i] = (*this)(i, i);
+    return d;
+  }
+  struct rowwise_proxy {
+    const cmatrix& a;
+    rarray<Rows> norm() const {
+      rarray<Rows> r;
+      a.rowwise_norm(r.v);
+      return r;
+    }
+  };
+  rowwise_proxy rowwise() const { return rowwise_proxy{*this}; }
   // sqrt(sum_j |a_ij|^2) for every row i (Eigen: rowwise().norm())
   void rowwise_norm(double* out) const {
     for (int i = 0; i < Rows; ++i) {

@@ -35,6 +35,9 @@ def build(ref=None):
         ref = os.path.isdir("/root/reference/inc")
     if ref:
         subprocess.run(["make", "-C", _HERE, "-s", "-j2", "ref"], check=True)
+        # the reference's unmodified drivers against the drop-in headers (needs the product library to link)
+        if os.path.exists(os.path.join(_HERE, "..", "blockcg_amd", "_build", "libblockcg_hip.so")):
+            subprocess.run(["make", "-C", _HERE, "-s", "-j2", "dropin"], check=True)
 
 
 def _dp(a):
