@@ -4,9 +4,17 @@
 A "step" is one SBCGrQ iteration (one pass of the loop body, inc/block_solvers.hpp:132-182) in
 fixed-work mode (eps = eps_shifts = 0: every shift stays active, work per iteration is constant).
 Workload at N = 1: BASELINE.json configs[2], V = 64^4, m = 16 right-hand sides, 4 shifts, fp64 --
-the largest configuration that fits one GPU (128^4 needs 2.4 TB).  For N > 1
-the lattice is domain-decomposed with 64^4 sites PER GPU (weak scaling; 8 GPUs = 64 x 128^3), one
-process per GPU, halo faces and the m x m all-reduce over torch.distributed / RCCL.
+the largest configuration that fits one GPU (128^4 needs 2.4 TB).
+
+N > 1 is the ladder that ends at the BASELINE headline, configs[3] (V = 128^4, m = 16, 4 shifts on 8 GPUs): every
+GPU holds 64 x 64 x 64 x 128 sites (279.5 GB of the 288 GB, capacity mode with a ring of 8 x3-slices) and the process
+grid grows over x2, x1, x0 with x3 undivided:
+    N = 2: 64 x 64 x 128 x 128 (grid 1,1,2,1)   N = 4: 64 x 128 x 128 x 128 (1,2,2,1)   N = 8: 128^4 (2,2,2,1)
+One process per GPU; halo faces (grouped ncclSend/ncclRecv) and the m x m all-reduce go over RCCL/xGMI through
+libblockcg_rccl.so (native code, include/blockcg_rccl.h); torch.distributed (gloo) is only the launcher's control plane
+(rendezvous of RCCL's unique id, the barrier around the timed region and the max over ranks).
+BCG_BACKEND=torch-nccl selects the torch.distributed RCCL transport of blockcg_amd/comm.py instead, BCG_BACKEND=gloo the
+host-staged one (several ranks sharing one GPU, rehearsals only).  --local-dims / --capacity override the shape.
 
 Prints ONE JSON line on rank 0.  `value` = lattice-site iterations per second summed over all
 GPUs (iterations/s x global volume) with all inputs resident in HBM; iterations/s and the achieved
@@ -77,25 +85,38 @@ def cpu_baseline(m, S, shifts, mass, budget_iters=32):
             "iterations_per_sec_at_sample": budget_iters / dt}
 
 
+def resolve_shape(world, local_dims, capacity):
+    """(sites per GPU, capacity ring, on-the-headline-ladder?) for a world size: the defaults documented at the top."""
+    ladder = world > 1 and local_dims is None
+    if local_dims is None:
+        local_dims = [64, 64, 64, 128] if world > 1 else [64, 64, 64, 64]
+    if capacity is None:
+        capacity = 8 if ladder else 0
+    return list(local_dims), capacity, ladder
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--local-dims", type=int, nargs="+", default=[64, 64, 64, 64])
+    ap.add_argument("--local-dims", type=int, nargs="+", default=None,
+                    help="sites per GPU (default: 64 64 64 64 on one GPU, 64 64 64 128 on several)")
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--shifts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic VALU kernels")
-    ap.add_argument("--capacity", type=int, default=0, metavar="R",
+    ap.add_argument("--capacity", type=int, default=None, metavar="R",
                     help="capacity mode: keep the operator's intermediate field as a ring of R x3 slices "
-                         "(bcg_capacity_mode); the process grid then leaves x3 undivided")
+                         "(bcg_capacity_mode); the process grid then leaves x3 undivided "
+                         "(default: 0 on one GPU, 8 on several with the default shape)")
     args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity)
 
     import torch
     import blockcg_amd as bc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = int(os.environ.get("BCG_DEVICE", local_rank))  # BCG_DEVICE: rehearse several ranks on one GPU (with gloo)
@@ -104,21 +125,34 @@ def main():
     dist = None
     comm = None
     ndim = len(args.local_dims)
+    transport = "none"
     if world > 1:
         import torch.distributed as dist
         from blockcg_amd.comm import TorchDistComm, coords_of, grid_for
         torch.cuda.set_device(device)
-        backend = os.environ.get("BCG_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
-        dist.init_process_group(backend=backend, device_id=torch.device("cuda", device) if backend == "nccl" else None)
+        transport = os.environ.get("BCG_BACKEND", "rccl")
+        if transport not in ("rccl", "torch-nccl", "gloo"):
+            sys.exit(f"BCG_BACKEND={transport}: expected rccl (native, default), torch-nccl or gloo")
+        if transport == "torch-nccl":  # torch's "nccl" backend is RCCL on ROCm
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")  # control plane only when transport == "rccl"
         grid = grid_for(world, ndim, keep_last=args.capacity > 0)
         if os.environ.get("BCG_BENCH_GRID"):  # rehearsal aid: an explicit process grid, e.g. "1,1,2,1"
             grid = [int(x) for x in os.environ["BCG_BENCH_GRID"].split(",")]
             assert len(grid) == ndim and int(__import__("math").prod(grid)) == world
         coords = coords_of(rank, grid)
-        comm = TorchDistComm(device)
         gdims = [l * g for l, g in zip(args.local_dims, grid)]
-        ctx = bc.Context(gdims, device=device, grid=grid, coords=coords, stream=comm.stream_ptr)
-        comm.attach(ctx)
+        if transport == "rccl":
+            from blockcg_amd import rccl
+            uid = [rccl.get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx = bc.Context(gdims, device=device, grid=grid, coords=coords)
+            comm = rccl.RcclComm(ctx, uid[0], rank, world)
+        else:
+            comm = TorchDistComm(device)
+            ctx = bc.Context(gdims, device=device, grid=grid, coords=coords, stream=comm.stream_ptr)
+            comm.attach(ctx)
     else:
         grid = [1] * ndim
         gdims = list(args.local_dims)
@@ -160,6 +194,8 @@ def main():
     st.end()
     if comm is not None and comm.error is not None:
         raise comm.error
+    if transport == "rccl":
+        comm.close()
 
     if rank == 0:
         Vg = 1
@@ -175,23 +211,38 @@ def main():
             name = max((k for k in prof if not k.startswith("stencil_form_")), key=lambda k: prof[k]["ms"])
             avg_ms = prof[name]["ms"] / prof[name]["count"]
             kb = kernel_bytes(name, ctx.V, m, S, ndim)
-            traffic = None
+            # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes
+            # (tools/profile_round.sh -> profiles/hbm_traffic.json); they are quoted only for the shape they were taken at
+            traffic, traffic_source, stencil_ratio = None, None, None
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(name, {}).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                shape = tj.get("_shape", {})
+                if (shape.get("local_dims") == list(args.local_dims) and shape.get("m") == m and shape.get("n_shifts") == S
+                        and shape.get("capacity", 0) == args.capacity and world == 1):
+                    traffic = tj.get(name, {}).get("bytes_per_launch")
+                    traffic_source = f"profiles/hbm_traffic.json ({shape.get('measured', 'separate rocprofv3 --pmc passes')})"
+                    sr = {}
+                    for kn in ("hop", "hop_shifted_gram"):
+                        if kn in tj and kernel_bytes(kn, ctx.V, m, S, ndim):
+                            sr[kn] = tj[kn]["bytes_per_launch"] / kernel_bytes(kn, ctx.V, m, S, ndim)
+                    stencil_ratio = sr or None
             if kb is not None:
                 ach = kb / (avg_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                        "launches": prof[name]["count"], "algorithmic_bytes_per_launch": kb}
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                        "avg_launch_ms": avg_ms, "launches": prof[name]["count"], "algorithmic_bytes_per_launch": kb,
+                        "stencil_traffic_ratio": stencil_ratio}
         out = {
             "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
             "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
-                                   f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)",
-                       "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts},
+                                   f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)"
+                                   + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
+                                      "(64^3x128 per GPU, capacity ring 8)" if headline_ladder or world == 1 else ""),
+                       "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
             "iterations_per_sec": its,
             "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,
             "hbm_roofline_frac_whole_iteration": hbm_gbps / world / HBM_PEAK_GBPS,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "bcg_halo_buffers": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                         c_size_p]),
     "bcg_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "bcg_context_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), c_int_p]),
+    "bcg_overlap_tuning": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bcg_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bcg_profile_json": (ctypes.c_char_p, [ctypes.c_void_p]),
     "bcg_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),

@@ -719,6 +719,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_ROW_BLOCKS_C")) c->row_blocks_C = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_WALK")) c->hop_tune.patch_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BLOCKS")) c->hop_tune.blocks = std::atoi(e);
+  if (const char* e = std::getenv("BCG_HOP_BLOCKS_OVERLAP")) c->hop_tune.blocks_overlap = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_SYNC")) c->hop_tune.sync.window = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_SYNC_LIMIT")) c->hop_tune.sync.limit_ticks = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
@@ -814,6 +815,19 @@ int bcg_debug_read_scratch(bcg_context* c, void* host, size_t bytes) {
   if (!c || !host || !c->partials || bytes > c->partials_bytes) return BCG_ERR_INVALID;
   BCG_TRY(stream_sync(c));
   HIP_TRY(c, hipMemcpy(host, c->partials, bytes, hipMemcpyDeviceToHost));
+  return BCG_OK;
+}
+
+int bcg_context_stream(const bcg_context* c, void** stream_out, int* device_out) {
+  if (!c) return BCG_ERR_INVALID;
+  if (stream_out) *stream_out = c->stream;
+  if (device_out) *device_out = c->device;
+  return BCG_OK;
+}
+
+int bcg_overlap_tuning(bcg_context* c, int interior_blocks) {
+  if (!c || interior_blocks < 0 || interior_blocks > kMaxGramBlocks / 2) return BCG_ERR_INVALID;
+  if (interior_blocks > 0) c->hop_tune.blocks_overlap = interior_blocks;
   return BCG_OK;
 }
 

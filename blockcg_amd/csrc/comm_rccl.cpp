@@ -1,0 +1,214 @@
+// libblockcg_rccl.so: bcg_comm on RCCL (include/blockcg_rccl.h).  Host code only; the transfers are RCCL's kernels.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "../../include/blockcg_rccl.h"
+
+static_assert(BCG_RCCL_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+
+struct bcg_rccl_comm {
+  bcg_context* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t ctx_stream = nullptr;   // the context's stream (not owned)
+  hipStream_t xfer_stream = nullptr;  // split exchange: higher priority than the compute stream
+  hipEvent_t packed = nullptr, arrived = nullptr;
+  double* scratch = nullptr;          // one device double for barrier / max
+  bcg_comm table{};
+  std::string err;
+};
+
+namespace {
+
+std::string g_err;
+
+bool fail(bcg_rccl_comm* c, const std::string& msg) {
+  if (c) c->err = msg;
+  else g_err = msg;
+  return false;
+}
+#define RCCL_OK(c, call)                                                                     \
+  do {                                                                                       \
+    ncclResult_t r_ = (call);                                                                \
+    if (r_ != ncclSuccess) { fail(c, std::string(#call) + ": " + ncclGetErrorString(r_)); return 1; } \
+  } while (0)
+#define HIP_OK(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) { fail(c, std::string(#call) + ": " + hipGetErrorString(e_)); return 1; } \
+  } while (0)
+
+// All messages of one exchange as ONE RCCL group on `stream`: every rank posts its sends and receives together, so
+// the point-to-point kernels pair up whatever order the peers appear in.  Two messages to the same peer (a direction
+// split over two ranks: the plus and the minus neighbour coincide) are matched by posting order, which is the same
+// ascending-direction, low-face-first order on both sides (bcg_halo_plan).
+int post_group(bcg_rccl_comm* c, hipStream_t stream, int n, const int* peer_send, const int* peer_recv,
+               const size_t* off_s, const size_t* off_r, const size_t* nbytes) {
+  void *send = nullptr, *recv = nullptr;
+  size_t each = 0;
+  if (bcg_halo_buffers(c->ctx, &send, &recv, &each) != BCG_OK) { fail(c, "bcg_halo_buffers failed"); return 1; }
+  for (int k = 0; k < n; ++k) {  // validate before the group opens: an error inside it would leave it open
+    if (off_s[k] + nbytes[k] > each || off_r[k] + nbytes[k] > each) { fail(c, "halo message outside the halo buffers"); return 1; }
+    if (peer_send[k] < 0 || peer_send[k] >= c->world || peer_recv[k] < 0 || peer_recv[k] >= c->world) {
+      fail(c, "halo peer rank outside the communicator (process grid and world size disagree)");
+      return 1;
+    }
+  }
+  RCCL_OK(c, ncclGroupStart());
+  for (int k = 0; k < n; ++k) {
+    RCCL_OK(c, ncclSend(static_cast<const char*>(send) + off_s[k], nbytes[k], ncclChar, peer_send[k], c->comm, stream));
+    RCCL_OK(c, ncclRecv(static_cast<char*>(recv) + off_r[k], nbytes[k], ncclChar, peer_recv[k], c->comm, stream));
+  }
+  RCCL_OK(c, ncclGroupEnd());
+  return 0;
+}
+
+int cb_halo(void* user, int n, const int* ps, const int* pr, const size_t* os, const size_t* orr, const size_t* nb) {
+  bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
+  return post_group(c, c->ctx_stream, n, ps, pr, os, orr, nb);
+}
+int cb_halo_begin(void* user, int n, const int* ps, const int* pr, const size_t* os, const size_t* orr, const size_t* nb) {
+  bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
+  HIP_OK(c, hipEventRecord(c->packed, c->ctx_stream));            // the faces are packed once this fires
+  HIP_OK(c, hipStreamWaitEvent(c->xfer_stream, c->packed, 0));
+  if (post_group(c, c->xfer_stream, n, ps, pr, os, orr, nb) != 0) return 1;
+  HIP_OK(c, hipEventRecord(c->arrived, c->xfer_stream));
+  return 0;
+}
+int cb_halo_end(void* user) {
+  bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
+  HIP_OK(c, hipStreamWaitEvent(c->ctx_stream, c->arrived, 0));    // boundary tiles read the ghosts after this
+  return 0;
+}
+int cb_allreduce(void* user, void* buf, size_t count) {
+  bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
+  RCCL_OK(c, ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->ctx_stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bcg_rccl_last_error(const bcg_rccl_comm* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int bcg_rccl_get_unique_id(void* out) {
+  if (!out) return BCG_ERR_INVALID;
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { g_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return BCG_ERR_COMM; }
+  std::memcpy(out, &id, sizeof id);
+  return BCG_OK;
+}
+
+int bcg_rccl_unique_id_via_file(const char* path, int rank, double timeout_s, void* out) {
+  if (!path || !out) return BCG_ERR_INVALID;
+  if (rank == 0) {
+    if (bcg_rccl_get_unique_id(out) != BCG_OK) return BCG_ERR_COMM;
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string(static_cast<long>(getpid()));
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(out, 1, BCG_RCCL_UNIQUE_ID_BYTES, f) != BCG_RCCL_UNIQUE_ID_BYTES) {
+      if (f) std::fclose(f);
+      g_err = "cannot write the unique id file " + tmp;
+      return BCG_ERR_COMM;
+    }
+    std::fclose(f);
+    if (std::rename(tmp.c_str(), path) != 0) { g_err = "cannot rename the unique id file"; return BCG_ERR_COMM; }
+    return BCG_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    if (FILE* f = std::fopen(path, "rb")) {
+      const size_t n = std::fread(out, 1, BCG_RCCL_UNIQUE_ID_BYTES, f);
+      std::fclose(f);
+      if (n == BCG_RCCL_UNIQUE_ID_BYTES) return BCG_OK;  // rename() made it appear complete
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      g_err = std::string("timed out waiting for the unique id file ") + path;
+      return BCG_ERR_COMM;
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+}
+
+int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int world, bcg_rccl_comm** out) {
+  if (!ctx || !id_bytes || !out || world < 1 || rank < 0 || rank >= world) {
+    g_err = "bcg_comm_rccl_create: bad arguments";
+    return BCG_ERR_INVALID;
+  }
+  bcg_rccl_comm* c = new bcg_rccl_comm();
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  void* s = nullptr;
+  auto bail = [&](const std::string& m, int code) {
+    g_err = m + (c->err.empty() ? "" : ": " + c->err);
+    bcg_comm_rccl_destroy(c);
+    return code;
+  };
+  if (bcg_context_stream(ctx, &s, &c->device) != BCG_OK) return bail("bcg_context_stream failed", BCG_ERR_INVALID);
+  c->ctx_stream = static_cast<hipStream_t>(s);
+  if (hipSetDevice(c->device) != hipSuccess) return bail("hipSetDevice failed", BCG_ERR_HIP);
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) return bail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r), BCG_ERR_COMM);
+  int lo = 0, hi = 0;  // numerically lower = higher priority
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+  if (hipStreamCreateWithPriority(&c->xfer_stream, hipStreamNonBlocking, hi) != hipSuccess ||
+      hipEventCreateWithFlags(&c->packed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->scratch), sizeof(double)) != hipSuccess)
+    return bail("stream/event/scratch creation failed", BCG_ERR_HIP);
+  c->table.user = c;
+  c->table.halo_exchange = cb_halo;
+  c->table.allreduce_sum = cb_allreduce;
+  c->table.halo_exchange_begin = cb_halo_begin;
+  c->table.halo_exchange_end = cb_halo_end;
+  if (bcg_context_set_comm(ctx, &c->table) != BCG_OK) return bail("bcg_context_set_comm failed", BCG_ERR_INVALID);
+  *out = c;
+  return BCG_OK;
+}
+
+const bcg_comm* bcg_comm_rccl_callbacks(const bcg_rccl_comm* c) { return c ? &c->table : nullptr; }
+
+int bcg_rccl_max_double(bcg_rccl_comm* c, double* v) {
+  if (!c || !v) return BCG_ERR_INVALID;
+  if (hipMemcpyAsync(c->scratch, v, sizeof(double), hipMemcpyHostToDevice, c->ctx_stream) != hipSuccess) return BCG_ERR_HIP;
+  ncclResult_t r = ncclAllReduce(c->scratch, c->scratch, 1, ncclDouble, ncclMax, c->comm, c->ctx_stream);
+  if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return BCG_ERR_COMM; }
+  if (hipMemcpyAsync(v, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->ctx_stream) != hipSuccess ||
+      hipStreamSynchronize(c->ctx_stream) != hipSuccess)
+    return BCG_ERR_HIP;
+  return BCG_OK;
+}
+
+int bcg_rccl_barrier(bcg_rccl_comm* c) {
+  double one = 1.0;
+  return bcg_rccl_max_double(c, &one);
+}
+
+int bcg_comm_rccl_destroy(bcg_rccl_comm* c) {
+  if (!c) return BCG_OK;
+  if (c->ctx) (void)bcg_context_set_comm(c->ctx, nullptr);
+  if (c->ctx_stream) (void)hipStreamSynchronize(c->ctx_stream);
+  if (c->xfer_stream) {
+    (void)hipStreamSynchronize(c->xfer_stream);
+    (void)hipStreamDestroy(c->xfer_stream);
+  }
+  if (c->packed) (void)hipEventDestroy(c->packed);
+  if (c->arrived) (void)hipEventDestroy(c->arrived);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+  return BCG_OK;
+}
+
+}  // extern "C"

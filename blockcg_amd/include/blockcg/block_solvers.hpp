@@ -26,6 +26,27 @@ int SBCGrQ(std::vector<block_fermion_field<N_rhs>>& X, const block_fermion_field
   return iterations;
 }
 
+namespace blockcg {
+// The same solver, but B's storage becomes the residual block Q (the reference copies B into Q, :109): one field less
+// in HBM, which is what lets the 64^3 x 128 share of a 128^4 lattice fit one MI355X.  B's contents are destroyed.
+template <int N_rhs>
+int SBCGrQ_consuming_source(std::vector<block_fermion_field<N_rhs>>& X, block_fermion_field<N_rhs>& B, const dirac_op& D,
+                            std::vector<double>& sigma, double eps = 1.e-15, double eps_shifts = 1.e-15,
+                            int max_iterations = 1e6) {
+  if (sigma.size() != X.size()) throw std::invalid_argument("number of shifts does not match number of solution vectors");
+  std::vector<bcg_field*> Xh(X.size());
+  for (size_t s = 0; s < X.size(); ++s) Xh[s] = X[s].handle();
+  B.flush();
+  int iterations = 0;
+  check(bcg_sbcgrq_solve(D.lat().ctx(), D.handle(), D.mass, Xh.data(), B.handle(), static_cast<int>(X.size()), sigma.data(),
+                         eps, eps_shifts, max_iterations, /*consume_B=*/1, &iterations, nullptr, nullptr),
+        D.lat().ctx(), "SBCGrQ");
+  for (auto& x : X) x.device_written();
+  B.device_written();
+  return iterations;
+}
+}  // namespace blockcg
+
 // BCG inversion of D X = B (inc/block_solvers.hpp:10-12); returns the number of operator applications
 template <int N_rhs>
 int BCG(block_fermion_field<N_rhs>& X, const block_fermion_field<N_rhs>& B, const dirac_op& D, double eps = 1.e-15,

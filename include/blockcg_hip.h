@@ -100,6 +100,14 @@ int bcg_halo_plan(int ndim, const int* global_dims, const int* grid, const int* 
  * tensors. */
 int bcg_halo_buffers(bcg_context* ctx, void** send, void** recv, size_t* bytes_each);
 int bcg_synchronize(bcg_context* ctx);
+/* The hipStream_t every call on this context enqueues on and its HIP device ordinal (for a transport that must order its
+ * transfers with the library's kernels: include/blockcg_rccl.h). */
+int bcg_context_stream(const bcg_context* ctx, void** stream_out, int* device_out);
+/* Overlap tuning of the split halo exchange (bcg_comm.halo_exchange_begin/end).  interior_blocks: workgroups of the
+ * stencil launch over the interior tiles, which runs while the exchange is in flight (default 512 = 2 per CU; a smaller
+ * grid leaves compute units to the transport's kernels, at the price of a slower interior sweep; 0 keeps the current
+ * value).  Results do not depend on it.  Also settable with BCG_HOP_BLOCKS_OVERLAP at context creation. */
+int bcg_overlap_tuning(bcg_context* ctx, int interior_blocks);
 /* Per-kernel timing with HIP events on the context's stream (off by default).  Names and
  * accumulated milliseconds / launch counts are returned as a JSON string owned by the context. */
 int bcg_profiling(bcg_context* ctx, int enable);

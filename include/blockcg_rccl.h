@@ -1,0 +1,54 @@
+/* blockcg_rccl.h -- C ABI of libblockcg_rccl.so: the bcg_comm callbacks of include/blockcg_hip.h implemented
+ * directly on RCCL, for hosts that are not Python (the reference's host is C++: benchmark.cpp:36-40,87-103 is the
+ * calling shape; SURVEY.md section 8e: pairwise halo exchange = ncclSend/ncclRecv in a group, block dot-products
+ * finished with an all-reduce of 2 m^2 doubles).  No torch, no Python: one process per GPU links libblockcg_hip.so,
+ * this library and librccl.so.
+ *
+ * Usage, one process per GPU (examples/multi_gpu_solver.cpp):
+ *     rank 0:  bcg_rccl_get_unique_id(id)            and hands the 128 bytes to every rank (file, socket, MPI ...)
+ *     all   :  bcg_context_create(&ctx, device, NULL, ndim, global_dims, grid, coords)
+ *              bcg_comm_rccl_create(ctx, id, rank, world, &comm)   -- installs the callbacks on ctx
+ *              ... solve ...
+ *              bcg_comm_rccl_destroy(comm)  before  bcg_context_destroy(ctx)
+ * Ranks are the lexicographic index of the process-grid coordinates with direction 0 fastest, the numbering
+ * bcg_halo_plan uses for its peers.
+ *
+ * Stream order: the all-reduce and the blocking halo exchange are enqueued on the context's stream.  The split
+ * exchange (halo_exchange_begin/end) runs on a second, higher-priority stream of this library: begin makes that
+ * stream wait for the packed faces (an event on the context's stream) and posts the grouped sends/receives there;
+ * end makes the context's stream wait for their completion.  The host never blocks in a callback.
+ */
+#ifndef BLOCKCG_RCCL_H
+#define BLOCKCG_RCCL_H
+
+#include "blockcg_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCG_RCCL_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+typedef struct bcg_rccl_comm bcg_rccl_comm;
+
+/* ncclGetUniqueId: call on ONE rank, distribute the bytes to all. */
+int bcg_rccl_get_unique_id(void* id_bytes_out);
+/* File rendezvous for hosts without another channel: rank 0 creates the id and writes it to `path` (atomically, via a
+ * temporary name); the other ranks poll for the file (up to timeout_s seconds).  All ranks return the same id. */
+int bcg_rccl_unique_id_via_file(const char* path, int rank, double timeout_s, void* id_bytes_out);
+/* ncclCommInitRank on the context's device, then bcg_context_set_comm(ctx, the RCCL callbacks).  Collective over all
+ * `world` ranks.  world == 1 is allowed (the callbacks then only ever see messages to self). */
+int bcg_comm_rccl_create(bcg_context* ctx, const void* unique_id_bytes, int rank, int world, bcg_rccl_comm** out);
+/* The callback table that was installed (for callers that want to wrap or inspect it). */
+const bcg_comm* bcg_comm_rccl_callbacks(const bcg_rccl_comm* comm);
+/* Host-side helpers a multi-process driver needs around its timed region: a barrier (all-reduce of one element +
+ * stream synchronize) and the maximum of a host double over all ranks. */
+int bcg_rccl_barrier(bcg_rccl_comm* comm);
+int bcg_rccl_max_double(bcg_rccl_comm* comm, double* value_inout);
+int bcg_comm_rccl_destroy(bcg_rccl_comm* comm);
+const char* bcg_rccl_last_error(const bcg_rccl_comm* comm); /* comm may be NULL: last creation error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLOCKCG_RCCL_H */

@@ -111,6 +111,10 @@ class Oracle:
     def set_threads(self, n):
         return self.lib.orc_set_threads(int(n))
 
+    def set_gram_arith(self, mode):
+        """0: the reference's sequential site sums; 1: pairwise (device-like); 2: long double accumulation."""
+        return self.lib.orc_set_gram_arith(int(mode))
+
     # --- sampled evaluator: (D psi)(x), (A psi)(x) at chosen global sites of a generated lattice ---
     def hop_sampled(self, m, dims, seed_U, seed_psi, sites):
         sites = np.ascontiguousarray(sites, dtype=np.int64)

@@ -78,6 +78,12 @@ int orc_set_threads(int n) {
   return threads();
 }
 
+// Summation order of the Gram products (oracle::gram_arith()): 0 reference, 1 pairwise (device-like), 2 long double.
+int orc_set_gram_arith(int mode) {
+  gram_arith() = mode;
+  return gram_arith();
+}
+
 // Sampled evaluator (oracle.hpp): out[k] = (D psi)(sites[k]) resp. (A psi)(sites[k]), [nsites][m][3] complex, with U and
 // psi from the counter-based generator (seed_U, seed_psi); nothing of size V is allocated.
 int orc_hop_sampled(int m, int ndim, const int* dims, uint64_t seed_U, uint64_t seed_psi, int64_t nsites,

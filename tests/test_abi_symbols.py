@@ -19,8 +19,8 @@ def lib():
     return blockcg_amd.load()
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "blockcg_hip.h")).read()
+def _declared(header="blockcg_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(bcg_[a-z0-9_]+)\s*\(", src)))
 
@@ -37,10 +37,23 @@ def test_bindings_cover_the_header():
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
+def test_rccl_library_exports_its_header(lib):
+    """libblockcg_rccl.so (native RCCL bcg_comm, include/blockcg_rccl.h): builds, loads without a GPU and exports every
+    declared entry point; no transfer is attempted here."""
+    from blockcg_amd import rccl
+    rl = rccl.load()
+    names = [n for n in _declared("blockcg_rccl.h") if n != "bcg_comm"]
+    assert len(names) == 8 and sorted(rccl.SIGNATURES) == sorted(names)
+    for n in names:
+        assert hasattr(rl, n), n
+    hdr = open(os.path.join(ROOT, "include", "blockcg_rccl.h")).read()
+    assert int(re.search(r"BCG_RCCL_UNIQUE_ID_BYTES (\d+)", hdr).group(1)) == rccl.UNIQUE_ID_BYTES
+
+
 def test_header_is_plain_c(tmp_path):
     """The boundary is a C ABI: the header must compile as C99 with no C++ (or torch) types in any signature."""
     src = tmp_path / "use_header.c"
-    src.write_text('#include "blockcg_hip.h"\n'
+    src.write_text('#include "blockcg_hip.h"\n#include "blockcg_rccl.h"\n'
                    "int probe(void) { bcg_context* c = 0; size_t n = 0; bcg_comm k; (void)k;\n"
                    "  return bcg_sbcgrq_device_bytes(c, 16, 4, 1, &n) + bcg_capacity_mode(c, 0); }\n")
     out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),

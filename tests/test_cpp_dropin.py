@@ -147,3 +147,35 @@ def test_unmodified_reference_unit_tests_pass_on_the_gpu():
     r = subprocess.run([DROPIN["dropin_tests"]], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert re.search(r"All tests passed \(\d+ assertions? in \d+ test cases?\)", r.stdout), r.stdout[-2000:]
+
+
+# ---- native multi-GPU driver (examples/multi_gpu_solver.cpp: drop-in headers + libblockcg_rccl.so, no Python) --------
+def _build_multi_gpu_driver():
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "multi_gpu_solver")
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-I", INC, os.path.join(ROOT, "examples", "multi_gpu_solver.cpp"),
+           "-o", exe, "-L", LIBDIR, "-lblockcg_rccl", "-lblockcg_hip", f"-Wl,-rpath,{LIBDIR}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_multi_gpu_driver_builds():
+    import blockcg_amd
+    blockcg_amd.build()  # libblockcg_hip.so and libblockcg_rccl.so
+    assert os.path.exists(_build_multi_gpu_driver())
+
+
+@pytest.mark.gpu
+def test_multi_gpu_driver_world_of_one(tmp_path):
+    """The C++ multi-process driver with one rank: RCCL communicator of one, (1,1,1,1) grid, capacity ring on and off."""
+    exe = _build_multi_gpu_driver()
+    for ring in ("0", "4"):
+        idfile = str(tmp_path / f"id{ring}")
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run([exe, idfile, "16", "8", "8", "16", "1", "1", "1", "1", "0.3", "1e-9", ring], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "SBCGrQ_iterations" in r.stdout
+        res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
+        assert len(res) == 4 and max(res) < 2e-9

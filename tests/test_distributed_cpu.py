@@ -42,3 +42,24 @@ def test_grid_and_plan_consistency():
                 assert [nb for _, nb in lst] == [nb for _, nb in recvs], (world, r, peer)
                 # posting order per peer is what RCCL matches on: the k-th send to a peer pairs with its k-th receive
                 assert [k for k, _ in lst] == [k for k, _ in recvs]
+
+
+def test_bench_selects_the_headline_ladder():
+    """bench.py --gpus N without shape flags: N = 1 is 64^4 (BASELINE configs[2]); N = 2, 4, 8 keep 64^3 x 128 sites per
+    GPU in capacity mode (ring 8) on grids (1,1,2,1), (1,2,2,1), (2,2,2,1), so that N = 8 is the headline 128^4."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from blockcg_amd.comm import coords_of, grid_for
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.resolve_shape(1, None, None) == ([64, 64, 64, 64], 0, False)
+    want = {2: ([1, 1, 2, 1], [64, 64, 128, 128]), 4: ([1, 2, 2, 1], [64, 128, 128, 128]), 8: ([2, 2, 2, 1], [128] * 4)}
+    for n, (grid, gdims) in want.items():
+        local, cap, ladder = bench.resolve_shape(n, None, None)
+        assert (local, cap, ladder) == ([64, 64, 64, 128], 8, True)
+        g = grid_for(n, 4, keep_last=cap > 0)
+        assert g == grid and [l * x for l, x in zip(local, g)] == gdims
+        assert sorted(tuple(coords_of(r, g)) for r in range(n)) == sorted(set(tuple(coords_of(r, g)) for r in range(n)))
+    assert bench.resolve_shape(2, [16, 16, 16, 16], None) == ([16, 16, 16, 16], 0, False)  # explicit shape: no capacity mode

@@ -77,12 +77,22 @@ def test_solver_matches_reference_fixture(bc, orc, path):
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
     info = bc.SBCGrQ(X, B, D, shifts, eps, eps_s, trace_limit=5, return_info=True)
     ref_it = int(g["iterations"])
-    # +-1 at well-conditioned configurations.  At mass = 1e-3 (condition number ~1e6) the iteration count
-    # depends on rounding: the GPU's FMA arithmetic and tree-ordered reductions converge in ~7 % fewer
-    # iterations than the reference's sequential sums (1632 vs 1761 at config 0); the acceptance criterion
-    # there is the true residual below.
-    slack = max(1, int(0.10 * ref_it)) if mass < 0.01 else 1
-    assert abs(info["iterations"] - ref_it) <= slack
+    # +-1 at well-conditioned configurations.  At mass = 1e-3 (condition number ~1e6, BASELINE config 0) the count depends
+    # on the summation order of the two Gram products: the reference's one running sum over the sites loses more digits
+    # than the GPU's tree-shaped reductions, and needs ~6 % more iterations (1717 on the reference, 1725 on the oracle in
+    # the reference's order, 1625 on the oracle with pairwise site sums, 1632 on the GPU).  Shown on the CPU in
+    # tests/test_iteration_count_sensitivity.py; here the GPU must land within SURVEY Appendix F's +-2 % of the oracle
+    # run in the GPU's summation shape, and within 8 % of the reference's own count.
+    if mass < 0.01:
+        orc.set_gram_arith(1)
+        try:
+            tree_it = orc.sbcgrq(g["U"], dims, mass, g["B"], shifts, eps, eps_s)["iterations"]
+        finally:
+            orc.set_gram_arith(0)
+        assert abs(info["iterations"] - tree_it) <= int(0.02 * tree_it), (info["iterations"], tree_it, ref_it)
+        assert abs(info["iterations"] - ref_it) <= int(0.08 * ref_it)
+    else:
+        assert abs(info["iterations"] - ref_it) <= 1
     Xh = np.stack([x.download() for x in X])
     # the reference's acceptance criterion, recomputed independently on the CPU (test/solvers.cpp:104-116)
     res = orc.true_residuals(g["U"], dims, mass, g["B"], shifts, Xh)

@@ -3,7 +3,8 @@
 kernel class), applying the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 counters are in KiB; FETCH_SIZE reports half the bytes of wide coalesced reads, so it is doubled;
 WRITE_SIZE is exact for 16-B-per-lane streaming stores.
-Usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <out.json>"""
+Usage: python tools/make_traffic_json.py <fetch_dir> <write_dir> <out.json> [<bench line .json of the profiled command>]
+The optional bench line supplies the shape the counters were taken at ("_shape"), which bench.py checks before quoting them."""
 import collections
 import csv
 import glob
@@ -38,5 +39,11 @@ for k in sorted(set(fetch) | set(write)):
     wr = write.get(k, 0.0) * 1024
     out[k] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
               "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE, separate passes, averaged over launches"}
+if len(sys.argv) > 4:
+    b = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    per_gpu = [g // p for g, p in zip(b["config"]["global_dims"], b["config"]["process_grid"])]
+    out["_shape"] = {"local_dims": per_gpu, "m": b["config"]["m"], "n_shifts": len(b["config"]["shifts"]),
+                     "capacity": b.get("capacity_ring_slices", 0),
+                     "measured": "rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes of bench.py"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

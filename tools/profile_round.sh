@@ -17,7 +17,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch 
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write.err || { tail -5 $out/pmc_write.err; exit 1; }
 echo "write done"
-python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/hbm_traffic.json > /dev/null
+python tools/make_traffic_json.py $out/pmc_fetch $out/pmc_write $out/hbm_traffic.json $out/bench_under_rocprof.json > /dev/null
 (python tools/pmc_summary.py $out/pmc_fetch; python tools/pmc_summary.py $out/pmc_write) > $out/pmc_fetch_write.txt
 cp $out/hbm_traffic.json profiles/hbm_traffic.json  # on the GPU box only: copy gpurun_out/prof/hbm_traffic.json into profiles/ after the call
 python bench.py --steps 20 --warmup 3 > $out/bench_final.json 2>> $out/bench.err
