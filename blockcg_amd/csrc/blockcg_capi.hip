@@ -44,6 +44,23 @@ std::string g_create_error;
     if (rc_ != BCG_OK) return rc_; \
   } while (0)
 
+// Every entry point that allocates or launches runs with the context's device current and restores the caller's
+// afterwards: a host with several contexts (or one that switches devices between calls, as torch does) must not get
+// fields on the wrong GPU.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(const bcg_context* c) {
+    if (!c) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // ---- profiling: HIP events on the context's stream around each kernel class ------------------
 struct ProfScope {
   bcg_context* c;
@@ -672,7 +689,11 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
     return BCG_ERR_NO_DEVICE;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    g_create_error = "bcg_context_create: hipGetDeviceProperties failed";
+    return BCG_ERR_NO_DEVICE;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_create_error = std::string("bcg_context_create: device is not gfx950 (MI355X): ") + prop.gcnArchName;
     return BCG_ERR_NO_DEVICE;
   }
@@ -741,6 +762,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
 }
 
 int bcg_context_destroy(bcg_context* c) {
+  DeviceScope on_device(c);
   if (!c) return BCG_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -802,6 +824,7 @@ int bcg_halo_plan(int ndim, const int* global_dims, const int* grid, const int* 
 }
 
 int bcg_halo_buffers(bcg_context* c, void** send, void** recv, size_t* bytes_each) {
+  DeviceScope on_device(c);
   if (!c) return BCG_ERR_INVALID;
   if (send) *send = c->halo_send;
   if (recv) *recv = c->halo_recv;
@@ -812,6 +835,7 @@ int bcg_halo_buffers(bcg_context* c, void** send, void** recv, size_t* bytes_eac
 // Tuning aid, not part of the interface (no declaration in include/): copy the Gram scratch buffer to the host.
 // Builds with -DBCG_HOP4_TRACE leave per-tile time stamps of the plain stencil there (tools/hop_drift.py).
 int bcg_debug_read_scratch(bcg_context* c, void* host, size_t bytes) {
+  DeviceScope on_device(c);
   if (!c || !host || !c->partials || bytes > c->partials_bytes) return BCG_ERR_INVALID;
   BCG_TRY(stream_sync(c));
   HIP_TRY(c, hipMemcpy(host, c->partials, bytes, hipMemcpyDeviceToHost));
@@ -832,6 +856,7 @@ int bcg_overlap_tuning(bcg_context* c, int interior_blocks) {
 }
 
 int bcg_synchronize(bcg_context* c) {
+  DeviceScope on_device(c);
   if (!c) return BCG_ERR_INVALID;
   return stream_sync(c);
 }
@@ -844,6 +869,7 @@ int bcg_profiling(bcg_context* c, int enable) {
 }
 
 int bcg_profile_reset(bcg_context* c) {
+  DeviceScope on_device(c);
   if (!c) return BCG_ERR_INVALID;
   BCG_TRY(stream_sync(c));
   for (auto& kv : c->prof) {
@@ -854,6 +880,7 @@ int bcg_profile_reset(bcg_context* c) {
 }
 
 const char* bcg_profile_json(bcg_context* c) {
+  DeviceScope on_device(c);
   if (!c) return "{}";
   (void)stream_sync(c);
   std::ostringstream os;
@@ -877,6 +904,7 @@ int bcg_force_generic(bcg_context* c, int enable) {
 }
 
 int bcg_capacity_mode(bcg_context* c, int ring_slices) {
+  DeviceScope on_device(c);
   if (!c) return BCG_ERR_INVALID;
   if (ring_slices != 0) {
     if (c->lat.ndim != 4 || c->lat.split[3])
@@ -902,6 +930,7 @@ int bcg_capacity_mode(bcg_context* c, int ring_slices) {
 }
 
 int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consume_B, size_t* bytes_out) {
+  DeviceScope on_device(c);
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
   const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
   size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
@@ -915,6 +944,7 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
 
 // ---- fields ------------------------------------------------------------------------------------
 int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
+  DeviceScope on_device(c);
   if (!c || !out) return BCG_ERR_INVALID;
   if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
   bcg_field* f = new bcg_field{c, m, nullptr};
@@ -929,6 +959,7 @@ int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
 }
 
 int bcg_field_destroy(bcg_field* f) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f) return BCG_OK;
   (void)hipStreamSynchronize(f->ctx->stream);
   (void)hipFree(f->d);
@@ -939,6 +970,7 @@ int bcg_field_destroy(bcg_field* f) {
 int bcg_field_width(const bcg_field* f) { return f ? f->m : -1; }
 
 int bcg_field_upload(bcg_field* f, const double* host) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f || !host) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
@@ -956,6 +988,7 @@ int bcg_field_upload(bcg_field* f, const double* host) {
 }
 
 int bcg_field_download(const bcg_field* f, double* host) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f || !host) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
@@ -973,6 +1006,7 @@ int bcg_field_download(const bcg_field* f, double* host) {
 }
 
 int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites, double* host) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f || n < 0 || (n > 0 && (!sites || !host))) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   for (int64_t k = 0; k < n; ++k)
@@ -993,6 +1027,7 @@ int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites
 }
 
 int bcg_field_copy(bcg_field* dst, const bcg_field* src) {
+  DeviceScope on_device(dst ? dst->ctx : nullptr);
   if (!same_shape(dst, src)) return BCG_ERR_INVALID;
   bcg_context* c = dst->ctx;
   ProfScope ps(c, "copy");
@@ -1001,6 +1036,7 @@ int bcg_field_copy(bcg_field* dst, const bcg_field* src) {
 }
 
 int bcg_field_set_zero(bcg_field* f) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   ProfScope ps(c, "set_zero");
@@ -1009,6 +1045,7 @@ int bcg_field_set_zero(bcg_field* f) {
 }
 
 int bcg_field_fill_random(bcg_field* f, uint64_t seed) {
+  DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   bcg::launch_fill_field(c->stream, f->m, c->lat, c->gdims, f->d, seed);
@@ -1016,31 +1053,38 @@ int bcg_field_fill_random(bcg_field* f, uint64_t seed) {
 }
 
 int bcg_field_add_assign(bcg_field* y, const bcg_field* x) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x)) return BCG_ERR_INVALID;
   return axpby(y->ctx, y, 1.0, x, 1.0, "axpby");
 }
 int bcg_field_sub_assign(bcg_field* y, const bcg_field* x) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x)) return BCG_ERR_INVALID;
   return axpby(y->ctx, y, 1.0, x, -1.0, "axpby");
 }
 int bcg_field_add_scalar(bcg_field* y, const bcg_field* x, double a) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x)) return BCG_ERR_INVALID;
   return axpby(y->ctx, y, 1.0, x, a, "axpby");
 }
 int bcg_field_rescale_add_scalar(bcg_field* y, double a, const bcg_field* x, double b) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x)) return BCG_ERR_INVALID;
   return axpby(y->ctx, y, a, x, b, "axpby");
 }
 int bcg_field_add_matrix(bcg_field* y, const bcg_field* x, const double* M) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x) || !M || y == x) return BCG_ERR_INVALID;
   return rmul(y->ctx, y, x, CMat(y->m, M), 0.0, bcg::RMUL_ADD, "block_axpy");
 }
 int bcg_field_rescale_add_matrix(bcg_field* y, const double* M, const bcg_field* x, double b) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!same_shape(y, x) || !M) return BCG_ERR_INVALID;
   return rmul(y->ctx, y, x, CMat(y->m, M), b, bcg::RMUL_XPAY, "block_xpay");
 }
 
 int bcg_field_hermitian_dot(const bcg_field* a, const bcg_field* b, double* out) {
+  DeviceScope on_device(a ? a->ctx : nullptr);
   if (!same_shape(a, b) || !out) return BCG_ERR_INVALID;
   CMat G;
   BCG_TRY(gram(a->ctx, a, b, G));
@@ -1049,6 +1093,7 @@ int bcg_field_hermitian_dot(const bcg_field* a, const bcg_field* b, double* out)
 }
 
 int bcg_field_real_dot(const bcg_field* a, const bcg_field* b, double* out) {
+  DeviceScope on_device(a ? a->ctx : nullptr);
   if (!same_shape(a, b) || !out) return BCG_ERR_INVALID;
   if (a->m != 1) BCG_FAIL(a->ctx, BCG_ERR_INVALID, "real_dot is defined for N_rhs = 1 (inc/fields.hpp:93)");
   CMat G;
@@ -1058,11 +1103,13 @@ int bcg_field_real_dot(const bcg_field* a, const bcg_field* b, double* out) {
 }
 
 int bcg_field_tri_solve_rhs(bcg_field* y, const double* R) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!y || !R) return BCG_ERR_INVALID;
   return trisolve(y->ctx, y, CMat(y->m, R));
 }
 
 int bcg_field_thin_qr(bcg_field* y, double* R_out) {
+  DeviceScope on_device(y ? y->ctx : nullptr);
   if (!y || !R_out) return BCG_ERR_INVALID;
   CMat R;
   BCG_TRY(thin_qr(y->ctx, y, R));
@@ -1072,6 +1119,7 @@ int bcg_field_thin_qr(bcg_field* y, double* R_out) {
 
 // ---- operator ----------------------------------------------------------------------------------
 int bcg_gauge_create(bcg_context* c, bcg_gauge** out) {
+  DeviceScope on_device(c);
   if (!c || !out) return BCG_ERR_INVALID;
   bcg_gauge* g = new bcg_gauge{c, nullptr, nullptr, false};
   const size_t u_bytes = static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);
@@ -1092,6 +1140,7 @@ int bcg_gauge_create(bcg_context* c, bcg_gauge** out) {
 }
 
 int bcg_gauge_destroy(bcg_gauge* g) {
+  DeviceScope on_device(g ? g->ctx : nullptr);
   if (!g) return BCG_OK;
   (void)hipStreamSynchronize(g->ctx->stream);
   (void)hipFree(g->U);
@@ -1101,6 +1150,7 @@ int bcg_gauge_destroy(bcg_gauge* g) {
 }
 
 int bcg_gauge_upload(bcg_gauge* g, const double* host) {
+  DeviceScope on_device(g ? g->ctx : nullptr);
   if (!g || !host) return BCG_ERR_INVALID;
   bcg_context* c = g->ctx;
   HIP_TRY(c, hipMemcpyAsync(g->U, host, static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2),
@@ -1110,6 +1160,7 @@ int bcg_gauge_upload(bcg_gauge* g, const double* host) {
 }
 
 int bcg_gauge_fill_random(bcg_gauge* g, uint64_t seed) {
+  DeviceScope on_device(g ? g->ctx : nullptr);
   if (!g) return BCG_ERR_INVALID;
   bcg_context* c = g->ctx;
   bcg::launch_fill_gauge(c->stream, c->lat, c->gdims, g->U, seed);
@@ -1118,11 +1169,13 @@ int bcg_gauge_fill_random(bcg_gauge* g, uint64_t seed) {
 }
 
 int bcg_dirac_hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in) {
+  DeviceScope on_device(c);
   if (!c || !g || !same_shape(out, in) || out == in || g->ctx != c || in->ctx != c) return BCG_ERR_INVALID;
   return hop(c, g, out, in, bcg::HOP_PLAIN, nullptr, 0.0);
 }
 
 int bcg_dirac_apply(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* out, const bcg_field* in) {
+  DeviceScope on_device(c);
   if (!c || !g || !same_shape(out, in) || out == in || g->ctx != c || in->ctx != c) return BCG_ERR_INVALID;
   return apply_shifted(c, g, mass, 0.0, out, in);
 }
@@ -1166,6 +1219,7 @@ extern "C" {
 // res[s][i] = sqrt( (AX^dagger AX)_ii / (B^dagger B)_ii ).
 int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, const bcg_field* B,
                        int n_shifts, const double* sigma, double* res_out) {
+  DeviceScope on_device(c);
   if (!c || !g || !X || !B || !sigma || !res_out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
   const int m = B->m;
   FieldPool pool(c);
@@ -1186,6 +1240,7 @@ int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_fiel
 // CG (src/standard_solvers.cpp:3-32): single right-hand side, scalar coefficients.
 int bcg_cg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* x, const bcg_field* b, double eps,
                  int max_iterations, int* iterations_out) {
+  DeviceScope on_device(c);
   if (!c || !g || !same_shape(x, b) || x == b || g->ctx != c || b->ctx != c) return BCG_ERR_INVALID;
   if (b->m != 1) BCG_FAIL(c, BCG_ERR_INVALID, "CG takes fermion_field arguments (N_rhs = 1)");
   FieldPool pool(c);
@@ -1218,6 +1273,7 @@ int bcg_cg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* x, 
 // SCG (src/standard_solvers.cpp:34-95): multi-shift CG, scalar zeta/theta recurrences.
 int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* x, const bcg_field* b, int n_shifts,
                   const double* sigma, double eps, double eps_shifts, int max_iterations, int* iterations_out) {
+  DeviceScope on_device(c);
   if (!c || !g || !x || !b || !sigma || n_shifts < 1 || g->ctx != c || b->ctx != c) return BCG_ERR_INVALID;
   if (b->m != 1) BCG_FAIL(c, BCG_ERR_INVALID, "SCG takes fermion_field arguments (N_rhs = 1)");
   for (int s = 0; s < n_shifts; ++s)
@@ -1273,6 +1329,7 @@ int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* co
 // BCG (inc/block_solvers.hpp:10-45): block CG without the QR stabilisation.
 int bcg_bcg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
                   int max_iterations, int* iterations_out) {
+  DeviceScope on_device(c);
   if (!c || !g || !same_shape(X, B) || X == B || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
   const int m = B->m;
   FieldPool pool(c);
@@ -1311,6 +1368,7 @@ int bcg_bcg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X,
 // order (X += P alpha delta_old, Q -= T alpha, thinQR, P = P rho^dagger + Q, delta = rho delta).
 int bcg_bcgrq_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X, const bcg_field* B, double eps,
                     int max_iterations, int* iterations_out) {
+  DeviceScope on_device(c);
   const double zero = 0.0;
   bcg_field* Xs[1] = {X};
   return bcg_sbcgrq_solve(c, g, mass, Xs, const_cast<bcg_field*>(B), 1, &zero, eps, 0.0, max_iterations, 0, iterations_out,
@@ -1436,6 +1494,7 @@ extern "C" {
 
 int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
                      const double* sigma, double eps, double eps_shifts, int consume_B, bcg_sbcgrq_state** out) {
+  DeviceScope on_device(c);
   if (!c || !g || !X || !B || !sigma || !out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
   const int m = B->m;
   for (int s = 0; s < n_shifts; ++s)
@@ -1497,6 +1556,7 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
 
 int bcg_sbcgrq_iterate(bcg_sbcgrq_state* st, int max_new_iterations, int* iterations_total, double* residual_out,
                        bcg_sbcgrq_trace* trace) {
+  DeviceScope on_device(st ? st->c : nullptr);
   if (!st) return BCG_ERR_INVALID;
   int done = 0;
   while (st->residual > st->eps && done < max_new_iterations) {  // :132
@@ -1510,6 +1570,7 @@ int bcg_sbcgrq_iterate(bcg_sbcgrq_state* st, int max_new_iterations, int* iterat
 }
 
 int bcg_sbcgrq_end(bcg_sbcgrq_state* st) {
+  DeviceScope on_device(st ? st->c : nullptr);
   if (!st) return BCG_OK;
   (void)stream_sync(st->c);
   sbcgrq_release(st);
@@ -1520,6 +1581,7 @@ int bcg_sbcgrq_end(bcg_sbcgrq_state* st) {
 int bcg_sbcgrq_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* const* X, bcg_field* B, int n_shifts,
                      const double* sigma, double eps, double eps_shifts, int max_iterations, int consume_B,
                      int* iterations_out, double* residual_out, bcg_sbcgrq_trace* trace) {
+  DeviceScope on_device(c);
   bcg_sbcgrq_state* st = nullptr;
   if (trace) trace->recorded = 0;
   BCG_TRY(bcg_sbcgrq_begin(c, g, mass, X, B, n_shifts, sigma, eps, eps_shifts, consume_B, &st));

@@ -5,6 +5,14 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- FIRST, before libblockcg_hip.so is loaded: see "HIP runtime load order" below
+
+# HIP runtime load order.  This image's torch wheel bundles its own libamdhip64.so / libhsa-runtime64.so / librccl.so
+# (unversioned SONAMEs) next to the system ROCm ones the product links (libamdhip64.so.7, librccl.so.1).  Two ROCr
+# instances cannot both drive the GPU from one process: whichever initialises second sees "No HIP GPUs are available".
+# torch loads its bundle with RTLD_GLOBAL, so when torch is imported BEFORE the product library the library's HIP and RCCL
+# symbols bind to the bundle and the process has one runtime (this is what bench.py does).  Tests that use torch tensors
+# next to the library (halo buffer views, RCCL) therefore need this import order; the product itself never imports torch.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
