@@ -744,6 +744,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_SYNC")) c->hop_tune.sync.window = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_SYNC_LIMIT")) c->hop_tune.sync.limit_ticks = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_HOP_WAVE")) c->hop_tune.sync.wave_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);

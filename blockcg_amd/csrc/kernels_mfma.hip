@@ -1118,6 +1118,20 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
     fetch_back<SPB, RBM>(2, (g).x2, L2, S2, sp2, gm2, (g).x0b + L0 * ((g).x1 + L1 * (g).x3), (g).site0, U, Ughost, tid, rb2); \
     fetch_back<SPB, RBM>(3, (g).x3, L3, S3, sp3, gm3, (g).x0b + L0 * ((g).x1 + L1 * (g).x2), (g).site0, U, Ughost, tid, rb3); \
   }
+#ifdef BCG_HOP4C_STAMPS  // diagnostic build (tools/hop_stamps.py): where a tile's cycles go, summed per block by wave 0
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_amdgcn_s_memtime();
+#define BCG_STAMP(i)                                   \
+  {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    const long long t_ = __builtin_amdgcn_s_memtime(); \
+    seg[i] += t_ - tlast;                              \
+    tlast = t_;                                        \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  }
+#else
+#define BCG_STAMP(i)
+#endif
   int stage = 0;
   bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
   const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
@@ -1127,7 +1141,15 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
   // Tile classes (CLS 1: interior only, 2: boundary only; see k_hop4).  Every block still walks every tile number of
   // its class's sequence and counts the skipped ones as done, so the pacing counters keep their meaning.
 
-  for (int pi = cls * ppc; pi < (cls + 1) * ppc; ++pi) {
+  for (int pk = 0; pk < ppc; ++pk) {
+#ifdef BCG_HOP_INTERLEAVE
+    // the eight XCD classes work on eight ADJACENT patches at a time (a 4 x 2 x 1 super-patch): the halo rows one class
+    // fetches are interior rows of a neighbouring class's patch, fetched at about the same time, so the second fetch is
+    // served by the die-level Infinity Cache instead of HBM
+    const int pi = pk * 8 + cls;
+#else
+    const int pi = cls * ppc + pk;
+#endif
     const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
     const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
     const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
@@ -1137,7 +1159,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
       if (CLS == 0) return true;
       return (col_bnd || (sp3 && (x3 == 0 || x3 == L3 - 1))) == (CLS == 2);
     };
-    const int vs0 = (pi - cls * ppc) * win.x3_n - win.x3_lo;  // tile number of slice x3 in this block's sequence: vs0 + x3
+    const int vs0 = pk * win.x3_n - win.x3_lo;  // tile number of slice x3 in this block's sequence: vs0 + x3
     // ---- per-column constants of the six in-slice neighbour rows: site at x3 = 0, site stride per slice, buffer.
     // Field rows move by S3 per slice (by ring slots in capacity mode), ghost rows by the face's x3 stride.
 #define BCG_COL_DIR(XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AF, SF, KF, AB, SB, KB)                         \
@@ -1216,7 +1238,9 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
           }
         }
       }
+      BCG_STAMP(0)  // links parked, pacing wait
       __syncthreads();
+      BCG_STAMP(1)  // barrier
 #define BCG_PREFETCH_LINKS                                                                        \
   {                                                                                               \
     int nx = x3 + 1; /* the next tile of this launch in the column: its links are parked first thing there */ \
@@ -1286,6 +1310,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
         seen1_idx = step_n + 2 - hw.sync_window;
         seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
       }
+      BCG_STAMP(2)  // link prefetch and direction-0 loads issued
       double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
       const int x0 = x0b + sl;
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
@@ -1325,6 +1350,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
           acc[r].x = fma(eta, t[r].x, acc[r].x);
           acc[r].y = fma(eta, t[r].y, acc[r].y);
         }
+        BCG_STAMP(3 + mu)  // direction mu: wait for its rows + arithmetic (+ issue of the next direction's loads)
       }
       double2 tv[3];
 #pragma unroll
@@ -1340,9 +1366,17 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
       if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
         __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+      BCG_STAMP(7)  // p wait, stores, Gram step, counter
     }
   }
 #undef BCG_FETCH_LINKS
+#ifdef BCG_HOP4C_STAMPS
+  if (!GRAM && (tid & 63) == 0) {
+    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = static_cast<double>(seg[i]);
+  }
+#endif
+#undef BCG_STAMP
   if (GRAM) {
     if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
     else gram_block_store<16, NW>(G, smem, partials, tid);
@@ -1369,6 +1403,388 @@ k_hop4c_interior(LatticeDev lat, const double2* __restrict__ U, const double2* _
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// k_hop4w: the column sweep of k_hop4c with the four waves of a block made independent of each other.
+//
+// In-kernel stamps of k_hop4c (tools/hop_stamps.py, 64^4, m = 16) showed where a 12 400-cycle tile goes: 27 % in the
+// block barrier behind the cooperative link staging (the waves wait for the slowest), 13 % in an `s_waitcnt vmcnt(0)`
+// in front of the LDS writes of the links (the compiler cannot count the vector-memory operations since the link loads
+// across the tile's branches, so every tile drains the output stores it has just issued), and two serialised HBM-miss
+// latencies (vector memory returns in issue order: the next tile's links, issued first, hold back every L2 hit issued
+// after them, and the +x3 row / p miss again at the end).  Here
+//   * every wave stages the links of ITS OWN sites (SPW sites: a contiguous run of forward links, the U_0(x-0) of the
+//     site to its left, and the three backward links per site) in a private double-buffered LDS image: no __syncthreads
+//     in the loop, waves of a block drift freely;
+//   * everything that misses the L2 -- the +x3 row, p, and the NEXT tile's links -- is issued together, behind the last
+//     L2 hits of the tile, so there is one miss latency per tile and it overlaps the arithmetic of directions 2 and 3;
+//   * the links are parked in the other LDS image at the END of the tile, after the last use of loaded data and before
+//     the output stores are issued: the vmcnt(0) there waits for nothing that has not already been waited for;
+//   * pacing counts waves instead of blocks.
+// Same tiles, same arithmetic, same summation order as k_hop4c (bit-identical output).
+// ---------------------------------------------------------------------------------------------------
+template <int M, int MODE, bool GRAM, int CLS, bool RING>
+__device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2* __restrict__ U,
+                                           const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                           const double2* __restrict__ ghost, double2* __restrict__ out,
+                                           const double2* __restrict__ p, double c0, double2* __restrict__ partials,
+                                           const HopWalk& hw, const HopWindow& win) {
+  static_assert(!GRAM || M == 16 || M == 8, "fused Gram accumulation: lane&15 = rhs index (m = 16) or (site parity, rhs) (m = 8)");
+  constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
+  constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
+  constexpr int SPW = 64 / M;        // sites per wave
+  constexpr int SPB = 4 * SPW;       // sites per block tile
+  constexpr int NW = 4;
+  constexpr int NFW = (SPW + 1) * 36;  // per wave: forward links of its sites behind a slot for the site to their left (U_0 only)
+  constexpr int NBW = 3 * SPW * 9;   // per wave: backward links, directions 1..3
+  constexpr int STAGE = NFW + NBW;   // one link image of one wave (complex numbers)
+  constexpr int RFW = (SPW * 36 + 63) / 64;  // forward-link loads per lane
+  constexpr int RBK = (SPW * 9 + 63) / 64;   // backward-link loads per lane and direction
+  constexpr int RB = 3 * M * 16;  // bytes of one site row of a field
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  dv2* const Lw = reinterpret_cast<dv2*>(smem) + wave * 2 * STAGE;  // this wave's two link images
+  const int sw = lane / M;            // site within the wave
+  const int sl = wave * SPW + sw;     // site within the block tile
+  const int j = lane % M;
+  const unsigned voff = static_cast<unsigned>((sl * 3 * M + j) * 16);  // this lane's byte offset inside a tile row
+  const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
+  const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
+  const int sp0 = lat.split[0], sp1 = lat.split[1], sp2 = lat.split[2], sp3 = lat.split[3];
+  const int gm0 = static_cast<int>(lat.ghost_off[0][0]), gp0 = static_cast<int>(lat.ghost_off[0][1]);
+  const int gm1 = static_cast<int>(lat.ghost_off[1][0]), gp1 = static_cast<int>(lat.ghost_off[1][1]);
+  const int gm2 = static_cast<int>(lat.ghost_off[2][0]), gp2 = static_cast<int>(lat.ghost_off[2][1]);
+  const int gm3 = static_cast<int>(lat.ghost_off[3][0]), gp3 = static_cast<int>(lat.ghost_off[3][1]);
+  const int og0 = lat.origin[0], og1 = lat.origin[1], og2 = lat.origin[2];
+  const char* const inb = reinterpret_cast<const char*>(in);
+  const char* const ghb = reinterpret_cast<const char*>(ghost);
+  GramAcc<16> G;
+  if (GRAM) gram_zero(G);
+
+  const int r0 = hw.p0 / SPB, r1 = hw.p1, r4 = L0 / hw.p0, r5 = L1 / hw.p1, r6 = L2 / hw.p2;
+  const int cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int d0 = idx % r0, d1 = (idx / r0) % r1, d2 = idx / (r0 * r1);
+  const int ppc = (r4 * r5 * r6) >> 3;
+  const int x3_end = win.x3_lo + win.x3_n;
+
+  // which link element this lane stages: forward image element e = lane + 64 k (k < RFW), backward element likewise
+  // (direction 1 + e / (SPW*9), site (e / 9) % SPW, entry e % 9)
+  dv2 rf[RFW], rx, rb1[RBK], rb2[RBK], rb3[RBK];
+  rx = dv2{0.0, 0.0};
+  // per-lane constant byte offsets of the link loads: element `lane` (+ 64 k) of a contiguous run (forward links, left
+  // link), and entry c9 of site s of a backward run -- sites 36 complex numbers apart in the field, 9 in a ghost face
+  const unsigned fo = static_cast<unsigned>(lane) * 16;
+  unsigned bo_f[RBK], bo_g[RBK];
+#pragma unroll
+  for (int k = 0; k < RBK; ++k) {
+    const int e = lane + 64 * k;
+    bo_f[k] = static_cast<unsigned>((e / 9) * 36 + e % 9) * 16;
+    bo_g[k] = static_cast<unsigned>(e) * 16;
+  }
+#ifdef BCG_HOP4C_STAMPS  // diagnostic build (tools/hop_stamps.py): where a tile's cycles go, summed per wave
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_amdgcn_s_memtime();
+#define BCG_STAMP(i)                                   \
+  {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    const long long t_ = __builtin_amdgcn_s_memtime(); \
+    seg[i] += t_ - tlast;                              \
+    tlast = t_;                                        \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  }
+#else
+#define BCG_STAMP(i)
+#endif
+  int stage = 0;
+  bool pace = true;   // lane 0: still pacing against the other waves of the XCD class
+  const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
+  unsigned seen1 = 0, seen2 = 0;
+  int seen1_idx = -1, seen2_idx = -1;
+  const unsigned per = (gridDim.x >> 3) * NW;  // waves per XCD class
+
+  for (int pk = 0; pk < ppc; ++pk) {
+    const int pi = cls * ppc + pk;
+    const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
+    const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
+    const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
+    const bool col_bnd = (sp0 && (x0b == 0 || x0b + SPB == L0)) || (sp1 && (x1 == 0 || x1 == L1 - 1)) ||
+                         (sp2 && (x2 == 0 || x2 == L2 - 1));
+    auto wanted = [&](int x3) -> bool {
+      if (CLS == 0) return true;
+      return (col_bnd || (sp3 && (x3 == 0 || x3 == L3 - 1))) == (CLS == 2);
+    };
+    const int vs0 = pk * win.x3_n - win.x3_lo;  // tile number of slice x3 in this wave's sequence: vs0 + x3
+#define BCG_COL_DIR(XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AF, SF, KF, AB, SB, KB)                         \
+  int AF, SF, AB, SB;                                                                                     \
+  bool KF, KB;                                                                                            \
+  if ((XM) + 1 < (LM)) { AF = col + (SM); SF = S3; KF = false; }                                          \
+  else if (!(SPM)) { AF = col - ((LM) - 1) * (SM); SF = S3; KF = false; }                                 \
+  else { AF = (GPL) + (FIDX); SF = (FSTR); KF = true; }                                                   \
+  if ((XM) > 0) { AB = col - (SM); SB = S3; KB = false; }                                                 \
+  else if (!(SPM)) { AB = col + ((LM) - 1) * (SM); SB = S3; KB = false; }                                 \
+  else { AB = (GMN) + (FIDX); SB = (FSTR); KB = true; }
+    BCG_COL_DIR(x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_f1, s_f1, k_f1, a_b1, s_b1, k_b1)
+    BCG_COL_DIR(x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_f2, s_f2, k_f2, a_b2, s_b2, k_b2)
+#undef BCG_COL_DIR
+    const bool row_end = x0b + SPB == L0, row_start = x0b == 0;
+    const bool gh0p = row_end && sp0, gh0m = row_start && sp0;
+    int shift_p = 1, shift_m = -1;  // sites
+    unsigned voff_p = voff, voff_m = voff;
+    if (row_end) {
+      if (!sp0) { shift_p = 1 - L0; voff_p = (sl == SPB - 1) ? voff : voff + static_cast<unsigned>(L0) * RB; }
+      else voff_p = (sl == SPB - 1) ? voff - RB : voff;   // edge lane: any valid row, replaced from the ghost face
+    }
+    if (row_start) {
+      if (!sp0) voff_m = (sl == 0) ? voff + static_cast<unsigned>(L0) * RB : voff;
+      else voff_m = (sl == 0) ? voff + RB : voff;
+    }
+    // ---- link sources of this wave for slice x3: every load is a wave-uniform base plus a per-lane constant offset
+    // (fo / bo_f / bo_g below), so fetching costs no vector arithmetic inside the tile
+    const int swx = x0b + wave * SPW;  // x0 of the wave's first site
+    auto fetch_links = [&](int x3) __attribute__((always_inline)) {
+      const int64_t sw0 = static_cast<int64_t>(col) + wave * SPW + static_cast<int64_t>(x3) * S3;  // the wave's first site
+      const char* const fsrc = reinterpret_cast<const char*>(U) + sw0 * (36 * 16);
+      const char* lsrc;  // U_0 of the site to the left of the wave's first site
+      if (swx > 0) lsrc = reinterpret_cast<const char*>(U) + (sw0 - 1) * (36 * 16);
+      else if (!sp0) lsrc = reinterpret_cast<const char*>(U) + (sw0 + L0 - 1) * (36 * 16);
+      else lsrc = reinterpret_cast<const char*>(Ughost) + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + L2 * x3))) * (9 * 16);
+#pragma unroll
+      for (int k = 0; k < RFW; ++k)
+        if (lane + 64 * k < SPW * 36) rf[k] = *reinterpret_cast<const dv2*>(fsrc + fo + k * 1024);
+      if (lane < 9) rx = *reinterpret_cast<const dv2*>(lsrc + fo);
+      // backward links of direction mu: field links are 36 complex numbers apart per site, ghost links 9
+      const char* const ub_ = reinterpret_cast<const char*>(U);
+      const char* const ug_ = reinterpret_cast<const char*>(Ughost);
+      const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(x3) * s_b1 + wave * SPW;
+      const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(x3) * s_b2 + wave * SPW;
+      const char* const q1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
+      const char* const q2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
+      const char* q3;
+      bool k_b3 = false;
+      if (x3 > 0) q3 = ub_ + ((sw0 - S3) * 4 + 3) * (9 * 16);
+      else if (!sp3) q3 = ub_ + ((sw0 + static_cast<int64_t>(L3 - 1) * S3) * 4 + 3) * (9 * 16);
+      else { q3 = ug_ + (static_cast<int64_t>(gm3) + col + wave * SPW) * (9 * 16); k_b3 = true; }
+#pragma unroll
+      for (int k = 0; k < RBK; ++k)
+        if (lane + 64 * k < SPW * 9) {
+          rb1[k] = *reinterpret_cast<const dv2*>(q1 + (k_b1 ? bo_g[k] : bo_f[k]));
+          rb2[k] = *reinterpret_cast<const dv2*>(q2 + (k_b2 ? bo_g[k] : bo_f[k]));
+          rb3[k] = *reinterpret_cast<const dv2*>(q3 + (k_b3 ? bo_g[k] : bo_f[k]));
+        }
+    };
+    auto park_links = [&](int st) __attribute__((always_inline)) {
+      dv2* const Lf = Lw + st * STAGE;
+#pragma unroll
+      for (int k = 0; k < RFW; ++k)
+        if (lane + 64 * k < SPW * 36) Lf[36 + lane + 64 * k] = rf[k];
+      if (lane < 9) Lf[lane] = rx;
+#pragma unroll
+      for (int k = 0; k < RBK; ++k)
+        if (lane + 64 * k < SPW * 9) {
+          Lf[NFW + lane + 64 * k] = rb1[k];
+          Lf[NFW + SPW * 9 + lane + 64 * k] = rb2[k];
+          Lf[NFW + 2 * SPW * 9 + lane + 64 * k] = rb3[k];
+        }
+    };
+    int slot = RING ? win.x3_lo % win.ring : 0;
+    int links_in_lds = -1;  // slice whose links sit in the current LDS image
+    for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
+      const int step_n = vs0 + x3;
+      if (!wanted(x3)) {  // not this launch's tile: count it as done
+        if (hw.sync != nullptr && lane == 0 && step_n < hw.sync_stride)
+          __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+        continue;
+      }
+      if (links_in_lds != x3) {  // first tile of a run: fetch and park now, not overlapped
+        fetch_links(x3);
+        park_links(stage);
+        links_in_lds = x3;
+      }
+      int nx = x3 + 1;  // the next tile of this launch in the column: its links are fetched during this one
+      while (CLS != 0 && nx < x3_end && !wanted(nx)) ++nx;
+      if (hw.sync != nullptr && lane == 0 && pace) {  // pacing: all waves of this XCD class within `sync_window` slices
+        const int need = step_n - hw.sync_window;
+        const unsigned known = seen2_idx == need ? seen2 : (seen1_idx == need ? seen1 : 0u);
+        if (need >= 0 && known < per) {
+          unsigned* ctr = hw.sync + cls * hw.sync_stride + need;
+          const long long t0 = wall_clock64();
+          while (read_counter(ctr, zero_rt) < per) {
+            if (wall_clock64() - t0 > hw.sync_limit) {
+              pace = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+      BCG_STAMP(0)  // first-tile link fetch, pacing wait
+      const dv2* const Lf = Lw + stage * STAGE;
+      const dv2* const Lb = Lf + NFW;
+      // ---- the eight neighbour rows of this tile: scalar pointers
+      const int xf = RING_IN ? slot : x3;                       // where slice x3 of `in` lives
+      const int xfp = RING_IN ? (slot + 1 == win.ring ? 0 : slot + 1) : x3 + 1;
+      const int xfm = RING_IN ? (slot == 0 ? win.ring - 1 : slot - 1) : x3 - 1;
+#define BCG_ROW(A, S, K) ((K) ? ghb + static_cast<int64_t>((A) + x3 * (S)) * RB : inb + static_cast<int64_t>((A) + xf * (S)) * RB)
+      const char* const crow = inb + static_cast<int64_t>(col + xf * S3) * RB;
+      const char* const q_f0 = crow + static_cast<int64_t>(shift_p) * RB;
+      const char* const q_b0 = crow + static_cast<int64_t>(shift_m) * RB;
+      const char* const q_f1 = BCG_ROW(a_f1, s_f1, k_f1);
+      const char* const q_b1 = BCG_ROW(a_b1, s_b1, k_b1);
+      const char* const q_f2 = BCG_ROW(a_f2, s_f2, k_f2);
+      const char* const q_b2 = BCG_ROW(a_b2, s_b2, k_b2);
+#undef BCG_ROW
+      const char* q_f3;
+      const char* q_b3;
+      if (x3 + 1 < L3) q_f3 = inb + static_cast<int64_t>(col + xfp * S3) * RB;
+      else if (!sp3) q_f3 = inb + static_cast<int64_t>(col) * RB;  // slice 0 (slot 0: ring | L3)
+      else q_f3 = ghb + static_cast<int64_t>(gp3 + col) * RB;
+      if (x3 > 0) q_b3 = inb + static_cast<int64_t>(col + xfm * S3) * RB;
+      else if (!sp3) q_b3 = inb + static_cast<int64_t>(col + (RING_IN ? win.ring - 1 : L3 - 1) * S3) * RB;
+      else q_b3 = ghb + static_cast<int64_t>(gm3 + col) * RB;
+      double2 f[4][3], bk[4][3];
+      const char* const qf[4] = {q_f0, q_f1, q_f2, q_f3};
+      const char* const qb[4] = {q_b0, q_b1, q_b2, q_b3};
+#define BCG_LOAD_DIR(MU)                                                                   \
+  _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                          \
+    f[MU][k] = ld_sv(qf[MU], (MU) == 0 ? voff_p : voff, k * M * 16);                       \
+    bk[MU][k] = ld_sv(qb[MU], (MU) == 0 ? voff_m : voff, k * M * 16);                      \
+  }
+      BCG_LOAD_DIR(0)
+      if (gh0p || gh0m) {  // direction 0 divided over ranks: the edge site of an end-of-row tile reads the ghost face
+        const int64_t f0 = x1 + L1 * (x2 + L2 * x3);
+        if (gh0p && sl == SPB - 1) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) f[0][k] = ghost[(gp0 + f0) * 3 * M + k * M + j];
+        }
+        if (gh0m && sl == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bk[0][k] = ghost[(gm0 + f0) * 3 * M + k * M + j];
+        }
+      }
+      const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
+      const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
+      char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col + slot * S3) : crow_site) * RB;
+      double2 pv[3];
+      seen2 = seen1;
+      seen2_idx = seen1_idx;
+      if (hw.sync != nullptr && lane == 0 && pace && step_n + 2 >= hw.sync_window) {
+        seen1_idx = step_n + 2 - hw.sync_window;
+        seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
+      }
+      BCG_STAMP(1)  // direction-0 loads issued
+      BCG_STAMP(2)
+      double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+      const int x0 = x0b + sl;
+      const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
+#pragma unroll
+      for (int mu = 0; mu < 4; ++mu) {
+        if (mu == 0) { BCG_LOAD_DIR(1) }
+        if (mu == 1) { BCG_LOAD_DIR(2) }
+        if (mu == 2) {
+          // Vector memory returns in issue order, so what misses the L2 goes last and together: the new slice (+x3),
+          // p, and the links of the next tile (parked at the end of this one).
+          BCG_LOAD_DIR(3)
+          if (MODE == HOP_SHIFTED) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) pv[r] = ld_nt(reinterpret_cast<const double2*>(prow + voff + r * M * 16));
+          }
+          if (nx < x3_end) fetch_links(nx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
+        const double eta = (par & 1) ? -1.0 : 1.0;
+        const dv2* uf = Lf + (sw + 1) * 36 + mu * 9;
+        const dv2* ub = mu == 0 ? Lf + sw * 36 : Lb + ((mu - 1) * SPW + sw) * 9;
+        double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const dv2 u = uf[k * 3 + r];
+            t[r].x = fma(u.x, f[mu][k].x, t[r].x); t[r].x = fma(-u.y, f[mu][k].y, t[r].x);
+            t[r].y = fma(u.x, f[mu][k].y, t[r].y); t[r].y = fma(u.y, f[mu][k].x, t[r].y);
+            const dv2 v = ub[r * 3 + k];
+            t[r].x = fma(-v.x, bk[mu][k].x, t[r].x); t[r].x = fma(-v.y, bk[mu][k].y, t[r].x);
+            t[r].y = fma(-v.x, bk[mu][k].y, t[r].y); t[r].y = fma(v.y, bk[mu][k].x, t[r].y);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          acc[r].x = fma(eta, t[r].x, acc[r].x);
+          acc[r].y = fma(eta, t[r].y, acc[r].y);
+        }
+        // pin this direction's arithmetic here (see the note at the link staging below)
+        asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y));
+        BCG_STAMP(3 + mu)  // direction mu: wait for its rows + arithmetic (+ issue of the next direction's loads)
+      }
+#undef BCG_LOAD_DIR
+      double2 tv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+        else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+      }
+      // Pin the arithmetic in front of the (lane-predicated, hence branching) link staging below: the compiler otherwise sinks
+      // the FMAs of all four directions past those branches towards the stores, and everything they read -- 72 link
+      // entries -- stays live across them (255 VGPRs spilled).
+      asm volatile("" : "+v"(tv[0].x), "+v"(tv[0].y), "+v"(tv[1].x), "+v"(tv[1].y), "+v"(tv[2].x), "+v"(tv[2].y));
+      __builtin_amdgcn_sched_barrier(0);
+      // every load of this tile has been consumed: parking the next tile's links drains nothing new, and the output
+      // stores issued after it are never waited for inside the loop
+      stage ^= 1;
+      if (nx < x3_end) {
+        park_links(stage);
+        links_in_lds = nx;
+      }
+      __builtin_amdgcn_wave_barrier();  // the next tile's LDS reads (other lanes' writes) stay behind these writes
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+      if (GRAM) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
+      }
+      if (hw.sync != nullptr && lane == 0 && step_n < hw.sync_stride)
+        __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+      BCG_STAMP(7)  // p wait, link parking, stores, Gram step, counter
+    }
+  }
+#ifdef BCG_HOP4C_STAMPS
+  if (!GRAM && lane == 0) {
+    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = static_cast<double>(seg[i]);
+  }
+#endif
+#undef BCG_STAMP
+  if (GRAM) {
+    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
+    else gram_block_store<16, NW>(G, smem, partials, tid);
+  }
+}
+
+template <int M, int MODE, bool GRAM, int CLS, bool RING>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_hop4w(LatticeDev lat, const double2* __restrict__ U,
+                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                               const double2* __restrict__ ghost, double2* __restrict__ out,
+                                               const double2* __restrict__ p, double c0,
+                                               double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+  hop4w_body<M, MODE, GRAM, CLS, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
+}
+
+#ifdef BCG_PROBE  // tuning aid: compile only the probed stencil instantiations (seconds instead of minutes)
+template __global__ void k_hop4w<16, HOP_PLAIN, false, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                                  const double2*, double2*, const double2*, double, double2*,
+                                                                  HopWalk, HopWindow);
+template __global__ void k_hop4w<16, HOP_SHIFTED, true, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                                   const double2*, double2*, const double2*, double, double2*,
+                                                                   HopWalk, HopWindow);
+template __global__ void k_hop4c<16, HOP_PLAIN, false, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                                  const double2*, double2*, const double2*, double, double2*,
+                                                                  HopWalk, HopWindow);
+}  // namespace
+}  // namespace bcg
+#else
 inline int grid_tiles(int64_t ntiles, int per_block, int cap) {
   int64_t g = (ntiles + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -1591,6 +2007,32 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   if (pl.list && grid == 0) return 0;  // no boundary tiles
   const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
+  if (pl.column && tune.sync.wave_walk) {  // k_hop4w: the column sweep with independent waves
+    if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
+    constexpr int SPW = 64 / M;
+    const size_t lds_u = sizeof(double2) * 4 * 2 * ((SPW + 1) * 36 + 3 * SPW * 9);
+    const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+#define BCG_LAUNCH4W(MM, MD, GR, CL, RG)                                                                                \
+  do {                                                                                                                 \
+    allow_lds(k_hop4w<MM, MD, GR, CL, RG>, lds);                                                                       \
+    hipLaunchKernelGGL((k_hop4w<MM, MD, GR, CL, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                       c0, partials, hw, win);                                                                         \
+  } while (0)
+#define BCG_LAUNCH4W_R(MM, MD, GR)                          \
+  do {                                                      \
+    if (win.ring > 0) BCG_LAUNCH4W(MM, MD, GR, 0, true);    \
+    else if (cls == 1) BCG_LAUNCH4W(MM, MD, GR, 1, false);  \
+    else if (cls == 2) BCG_LAUNCH4W(MM, MD, GR, 2, false);  \
+    else BCG_LAUNCH4W(MM, MD, GR, 0, false);                \
+  } while (0)
+    if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4W_R(16, HOP_SHIFTED, true);
+    else if (gram && M == 8 && mode == HOP_SHIFTED) BCG_LAUNCH4W_R(8, HOP_SHIFTED, true);
+    else if (mode == HOP_PLAIN) BCG_LAUNCH4W_R(M, HOP_PLAIN, false);
+    else BCG_LAUNCH4W_R(M, HOP_SHIFTED, false);
+#undef BCG_LAUNCH4W_R
+#undef BCG_LAUNCH4W
+    return grid;
+  }
   if (pl.column) {
     if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
     const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
@@ -1689,3 +2131,4 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
 }
 
 }  // namespace bcg
+#endif  // BCG_PROBE

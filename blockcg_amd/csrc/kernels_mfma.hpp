@@ -30,6 +30,7 @@ struct HopSync {
                                  // measured at 64^4: 2 -> 13.3 ms, 3 -> 11.0, 4..8 -> 10.9 (unpaced 13.4)
   int limit_ticks = 5000;        // 100 MHz ticks (50 us) a block waits before it gives up pacing
   bool column_walk = true;       // use k_hop4c (scalar row pointers, column sweep) where the walk allows it
+  bool wave_walk = false;        // ... in its wave-independent form k_hop4w (no block barrier, links parked at the tile end): measured slower, see DESIGN.md
 };
 
 // Tuning of the specialised 4-D stencil (defaults chosen by measurement at 64^4, m = 16).
