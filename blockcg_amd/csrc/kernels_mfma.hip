@@ -1142,14 +1142,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
   // its class's sequence and counts the skipped ones as done, so the pacing counters keep their meaning.
 
   for (int pk = 0; pk < ppc; ++pk) {
-#ifdef BCG_HOP_INTERLEAVE
-    // the eight XCD classes work on eight ADJACENT patches at a time (a 4 x 2 x 1 super-patch): the halo rows one class
-    // fetches are interior rows of a neighbouring class's patch, fetched at about the same time, so the second fetch is
-    // served by the die-level Infinity Cache instead of HBM
-    const int pi = pk * 8 + cls;
-#else
     const int pi = cls * ppc + pk;
-#endif
     const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
     const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
     const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
@@ -1404,26 +1397,28 @@ k_hop4c_interior(LatticeDev lat, const double2* __restrict__ U, const double2* _
 
 
 // ---------------------------------------------------------------------------------------------------
-// k_hop4w: the column sweep of k_hop4c with the four waves of a block made independent of each other.
+// k_hop4b: the column sweep over BUNDLES of 2 x 2 columns.
 //
-// In-kernel stamps of k_hop4c (tools/hop_stamps.py, 64^4, m = 16) showed where a 12 400-cycle tile goes: 27 % in the
-// block barrier behind the cooperative link staging (the waves wait for the slowest), 13 % in an `s_waitcnt vmcnt(0)`
-// in front of the LDS writes of the links (the compiler cannot count the vector-memory operations since the link loads
-// across the tile's branches, so every tile drains the output stores it has just issued), and two serialised HBM-miss
-// latencies (vector memory returns in issue order: the next tile's links, issued first, hold back every L2 hit issued
-// after them, and the +x3 row / p miss again at the end).  Here
-//   * every wave stages the links of ITS OWN sites (SPW sites: a contiguous run of forward links, the U_0(x-0) of the
-//     site to its left, and the three backward links per site) in a private double-buffered LDS image: no __syncthreads
-//     in the loop, waves of a block drift freely;
-//   * everything that misses the L2 -- the +x3 row, p, and the NEXT tile's links -- is issued together, behind the last
-//     L2 hits of the tile, so there is one miss latency per tile and it overlaps the arithmetic of directions 2 and 3;
-//   * the links are parked in the other LDS image at the END of the tile, after the last use of loaded data and before
-//     the output stores are issued: the vmcnt(0) there waits for nothing that has not already been waited for;
-//   * pacing counts waves instead of blocks.
-// Same tiles, same arithmetic, same summation order as k_hop4c (bit-identical output).
+// Counters of k_hop4c at 64^4, m = 16 (tools/pmc_tcp_sq.sh): 138 GB pass through the L1s per launch, 58 % of it served
+// there and 61 % of the rest by the L2; the waves are parked on memory for 63 % of their cycles; and the time does not
+// follow the traffic (an x3 carry through LDS cut the fabric reads by 15 % and changed nothing).  With one row of
+// SPB consecutive x0 sites per block, every site costs 8 neighbour-row loads and all re-use is left to the caches.
+// Here a block's tile is SPW x 2 x 2 sites -- wave w owns the SPW consecutive x0 sites of row (x1 + (w & 1), x2 + (w >> 1))
+// -- and the rows a tile's sites share are loaded once and exchanged through LDS:
+//   * a wave loads ONE new row per step, its own +x3 row (with one halo site either side), uses it as the +x3
+//     neighbour and parks it in an LDS slot, where it serves at the next step as the wave's own x0 neighbours (the same
+//     row shifted by a site) and as the x1 / x2 neighbours of the other three waves, and at the step after that as the
+//     wave's own -x3 neighbour (read back just before the slot is overwritten);
+//   * only the two rows that leave the bundle (one in x1, one in x2) are fetched besides: 2 + 2/SPW + 1 + 1 row loads per
+//     site instead of 8 (4.5 at m = 16), 19 vector-memory instructions per wave and tile instead of 31;
+//   * links are staged per wave for its own sites and parked at the END of the step, behind the last use of loaded
+//     data and in front of the output stores (see there);
+// Tile order, XCD patches, pacing, x3 windows and ring addressing (capacity mode) and the fused Gram product are those
+// of k_hop4c; the interior / boundary tile classes of the split halo exchange stay with k_hop4c.  Same arithmetic per site
+// and the same order of the four directions, so results are bit-identical to k_hop4c.
 // ---------------------------------------------------------------------------------------------------
-template <int M, int MODE, bool GRAM, int CLS, bool RING>
-__device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2* __restrict__ U,
+template <int M, int MODE, bool GRAM, bool RING>
+__device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2* __restrict__ U,
                                            const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                            const double2* __restrict__ ghost, double2* __restrict__ out,
                                            const double2* __restrict__ p, double c0, double2* __restrict__ partials,
@@ -1431,22 +1426,30 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
   static_assert(!GRAM || M == 16 || M == 8, "fused Gram accumulation: lane&15 = rhs index (m = 16) or (site parity, rhs) (m = 8)");
   constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
-  constexpr int SPW = 64 / M;        // sites per wave
-  constexpr int SPB = 4 * SPW;       // sites per block tile
+  constexpr int SPW = 64 / M;              // sites per wave = tile extent in x0
   constexpr int NW = 4;
-  constexpr int NFW = (SPW + 1) * 36;  // per wave: forward links of its sites behind a slot for the site to their left (U_0 only)
-  constexpr int NBW = 3 * SPW * 9;   // per wave: backward links, directions 1..3
-  constexpr int STAGE = NFW + NBW;   // one link image of one wave (complex numbers)
-  constexpr int RFW = (SPW * 36 + 63) / 64;  // forward-link loads per lane
-  constexpr int RBK = (SPW * 9 + 63) / 64;   // backward-link loads per lane and direction
-  constexpr int RB = 3 * M * 16;  // bytes of one site row of a field
+  constexpr int CS = (SPW + 2) * 3 * M;    // one wave's row slot: halo site, SPW sites, halo site (complex numbers)
+  constexpr int NFW = (SPW + 1) * 36;      // link image of a wave: slot of the site to the left (U_0 only), forward links
+  constexpr int NBW = 3 * SPW * 9;         // ... backward links, directions 1..3
+  constexpr int LSTAGE = NFW + NBW;
+  constexpr int RFW = (SPW * 36 + 63) / 64;
+  constexpr int RBK = (SPW * 9 + 63) / 64;
+  constexpr int RB = 3 * M * 16;           // bytes of one site of a field
+  constexpr int NH = (2 * M + 63) / 64;    // halo loads per lane and colour (1)
+  static_assert(NH == 1, "halo sites fit one wave instruction per colour");
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  dv2* const Lw = reinterpret_cast<dv2*>(smem) + wave * 2 * STAGE;  // this wave's two link images
-  const int sw = lane / M;            // site within the wave
-  const int sl = wave * SPW + sw;     // site within the block tile
-  const int j = lane % M;
-  const unsigned voff = static_cast<unsigned>((sl * 3 * M + j) * 16);  // this lane's byte offset inside a tile row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int e1 = wave & 1, e2 = wave >> 1;
+  dv2* const Cbase = reinterpret_cast<dv2*>(smem);                       // [2 slots][4 waves][CS]
+  dv2* const Lw = Cbase + 2 * NW * CS + wave * 2 * LSTAGE;               // this wave's two link images
+  const int sw = lane / M, j = lane % M;
+  const unsigned voff = static_cast<unsigned>((sw * 3 * M + j) * 16);   // byte offset of (site sw, colour 0, rhs j) in a row
+  const int co = (sw + 1) * 3 * M + j;                                   // the same element in a row slot (colour c: + c*M)
+  // halo element of this lane (lanes < 2M): site hs (0 left, 1 right), rhs hj
+  const bool halo_lane = lane < 2 * M;
+  const int hs = (lane / M) & 1, hj = lane % M;
+  const int ho = (hs ? (SPW + 1) * 3 * M : 0) + hj;
   const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
   const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
   const int sp0 = lat.split[0], sp1 = lat.split[1], sp2 = lat.split[2], sp3 = lat.split[3];
@@ -1460,18 +1463,15 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
   GramAcc<16> G;
   if (GRAM) gram_zero(G);
 
-  const int r0 = hw.p0 / SPB, r1 = hw.p1, r4 = L0 / hw.p0, r5 = L1 / hw.p1, r6 = L2 / hw.p2;
+  // ---- this block's tile inside a patch, and the patches of its XCD class
+  const int r0 = hw.p0 / SPW, r1 = hw.p1 / 2, r4 = L0 / hw.p0, r5 = L1 / hw.p1, r6 = L2 / hw.p2;
   const int cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int d0 = idx % r0, d1 = (idx / r0) % r1, d2 = idx / (r0 * r1);
   const int ppc = (r4 * r5 * r6) >> 3;
   const int x3_end = win.x3_lo + win.x3_n;
 
-  // which link element this lane stages: forward image element e = lane + 64 k (k < RFW), backward element likewise
-  // (direction 1 + e / (SPW*9), site (e / 9) % SPW, entry e % 9)
   dv2 rf[RFW], rx, rb1[RBK], rb2[RBK], rb3[RBK];
   rx = dv2{0.0, 0.0};
-  // per-lane constant byte offsets of the link loads: element `lane` (+ 64 k) of a contiguous run (forward links, left
-  // link), and entry c9 of site s of a backward run -- sites 36 complex numbers apart in the field, 9 in a ghost face
   const unsigned fo = static_cast<unsigned>(lane) * 16;
   unsigned bo_f[RBK], bo_g[RBK];
 #pragma unroll
@@ -1480,99 +1480,81 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
     bo_f[k] = static_cast<unsigned>((e / 9) * 36 + e % 9) * 16;
     bo_g[k] = static_cast<unsigned>(e) * 16;
   }
-#ifdef BCG_HOP4C_STAMPS  // diagnostic build (tools/hop_stamps.py): where a tile's cycles go, summed per wave
-  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = __builtin_amdgcn_s_memtime();
-#define BCG_STAMP(i)                                   \
-  {                                                    \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    const long long t_ = __builtin_amdgcn_s_memtime(); \
-    seg[i] += t_ - tlast;                              \
-    tlast = t_;                                        \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  }
-#else
-#define BCG_STAMP(i)
-#endif
-  int stage = 0;
-  bool pace = true;   // lane 0: still pacing against the other waves of the XCD class
+  int lstage = 0;
+  bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
   const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
   unsigned seen1 = 0, seen2 = 0;
   int seen1_idx = -1, seen2_idx = -1;
-  const unsigned per = (gridDim.x >> 3) * NW;  // waves per XCD class
+  const unsigned per = gridDim.x >> 3;
 
   for (int pk = 0; pk < ppc; ++pk) {
     const int pi = cls * ppc + pk;
     const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
-    const int x0b = (d4 * r0 + d0) * SPB, x1 = d5 * hw.p1 + d1, x2 = d6 * hw.p2 + d2;
-    const int col = x0b + L0 * (x1 + L1 * x2);  // site of the column at x3 = 0
-    const bool col_bnd = (sp0 && (x0b == 0 || x0b + SPB == L0)) || (sp1 && (x1 == 0 || x1 == L1 - 1)) ||
-                         (sp2 && (x2 == 0 || x2 == L2 - 1));
-    auto wanted = [&](int x3) -> bool {
-      if (CLS == 0) return true;
-      return (col_bnd || (sp3 && (x3 == 0 || x3 == L3 - 1))) == (CLS == 2);
-    };
-    const int vs0 = pk * win.x3_n - win.x3_lo;  // tile number of slice x3 in this wave's sequence: vs0 + x3
-#define BCG_COL_DIR(XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AF, SF, KF, AB, SB, KB)                         \
-  int AF, SF, AB, SB;                                                                                     \
-  bool KF, KB;                                                                                            \
-  if ((XM) + 1 < (LM)) { AF = col + (SM); SF = S3; KF = false; }                                          \
-  else if (!(SPM)) { AF = col - ((LM) - 1) * (SM); SF = S3; KF = false; }                                 \
-  else { AF = (GPL) + (FIDX); SF = (FSTR); KF = true; }                                                   \
+    const int x0b = (d4 * r0 + d0) * SPW, x1 = d5 * hw.p1 + d1 * 2 + e1, x2 = d6 * hw.p2 + d2 * 2 + e2;
+    const int col = x0b + L0 * (x1 + L1 * x2);  // this wave's first site at x3 = 0
+    const int vs0 = pk * win.x3_n - win.x3_lo;  // tile number of slice x3 in this block's sequence: vs0 + x3
+    // ---- the row of this wave that leaves the bundle in direction 1 (forward if e1, else backward) and in direction 2:
+    // site at x3 = 0, site stride per slice, field (false) or ghost face (true) -- as in k_hop4c
+#define BCG_OUT_DIR(FWD, XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AO, SO, KO)                                \
+  int AO, SO;                                                                                             \
+  bool KO;                                                                                                \
+  if (FWD) {                                                                                              \
+    if ((XM) + 1 < (LM)) { AO = col + (SM); SO = S3; KO = false; }                                        \
+    else if (!(SPM)) { AO = col - ((LM) - 1) * (SM); SO = S3; KO = false; }                               \
+    else { AO = (GPL) + (FIDX); SO = (FSTR); KO = true; }                                                 \
+  } else {                                                                                                \
+    if ((XM) > 0) { AO = col - (SM); SO = S3; KO = false; }                                               \
+    else if (!(SPM)) { AO = col + ((LM) - 1) * (SM); SO = S3; KO = false; }                               \
+    else { AO = (GMN) + (FIDX); SO = (FSTR); KO = true; }                                                 \
+  }
+    BCG_OUT_DIR(e1, x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_o1, s_o1, k_o1)
+    BCG_OUT_DIR(e2, x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_o2, s_o2, k_o2)
+#undef BCG_OUT_DIR
+    // backward LINK rows of directions 1, 2 (U_mu(x - mu) lives at the backward neighbour site, whichever way the
+    // psi row of that direction comes in)
+#define BCG_BACK_DIR(XM, LM, SM, SPM, GMN, FIDX, FSTR, AB, SB, KB)                                         \
+  int AB, SB;                                                                                             \
+  bool KB;                                                                                                \
   if ((XM) > 0) { AB = col - (SM); SB = S3; KB = false; }                                                 \
   else if (!(SPM)) { AB = col + ((LM) - 1) * (SM); SB = S3; KB = false; }                                 \
   else { AB = (GMN) + (FIDX); SB = (FSTR); KB = true; }
-    BCG_COL_DIR(x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_f1, s_f1, k_f1, a_b1, s_b1, k_b1)
-    BCG_COL_DIR(x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_f2, s_f2, k_f2, a_b2, s_b2, k_b2)
-#undef BCG_COL_DIR
-    const bool row_end = x0b + SPB == L0, row_start = x0b == 0;
-    const bool gh0p = row_end && sp0, gh0m = row_start && sp0;
-    int shift_p = 1, shift_m = -1;  // sites
-    unsigned voff_p = voff, voff_m = voff;
-    if (row_end) {
-      if (!sp0) { shift_p = 1 - L0; voff_p = (sl == SPB - 1) ? voff : voff + static_cast<unsigned>(L0) * RB; }
-      else voff_p = (sl == SPB - 1) ? voff - RB : voff;   // edge lane: any valid row, replaced from the ghost face
-    }
-    if (row_start) {
-      if (!sp0) voff_m = (sl == 0) ? voff + static_cast<unsigned>(L0) * RB : voff;
-      else voff_m = (sl == 0) ? voff + RB : voff;
-    }
-    // ---- link sources of this wave for slice x3: every load is a wave-uniform base plus a per-lane constant offset
-    // (fo / bo_f / bo_g below), so fetching costs no vector arithmetic inside the tile
-    const int swx = x0b + wave * SPW;  // x0 of the wave's first site
+    BCG_BACK_DIR(x1, L1, S1, sp1, gm1, x0b + L0 * x2, L0 * L2, a_b1, s_b1, k_b1)
+    BCG_BACK_DIR(x2, L2, S2, sp2, gm2, x0b + L0 * x1, L0 * L1, a_b2, s_b2, k_b2)
+#undef BCG_BACK_DIR
+    const bool row_end = x0b + SPW == L0, row_start = x0b == 0;
+
     auto fetch_links = [&](int x3) __attribute__((always_inline)) {
-      const int64_t sw0 = static_cast<int64_t>(col) + wave * SPW + static_cast<int64_t>(x3) * S3;  // the wave's first site
+      const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;  // the wave's first site
       const char* const fsrc = reinterpret_cast<const char*>(U) + sw0 * (36 * 16);
       const char* lsrc;  // U_0 of the site to the left of the wave's first site
-      if (swx > 0) lsrc = reinterpret_cast<const char*>(U) + (sw0 - 1) * (36 * 16);
+      if (!row_start) lsrc = reinterpret_cast<const char*>(U) + (sw0 - 1) * (36 * 16);
       else if (!sp0) lsrc = reinterpret_cast<const char*>(U) + (sw0 + L0 - 1) * (36 * 16);
       else lsrc = reinterpret_cast<const char*>(Ughost) + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + L2 * x3))) * (9 * 16);
 #pragma unroll
       for (int k = 0; k < RFW; ++k)
-        if (lane + 64 * k < SPW * 36) rf[k] = *reinterpret_cast<const dv2*>(fsrc + fo + k * 1024);
-      if (lane < 9) rx = *reinterpret_cast<const dv2*>(lsrc + fo);
-      // backward links of direction mu: field links are 36 complex numbers apart per site, ghost links 9
+        if (lane + 64 * k < SPW * 36) rf[k] = ld_link(reinterpret_cast<const dv2*>(fsrc + fo + k * 1024));
+      if (lane < 9) rx = ld_link(reinterpret_cast<const dv2*>(lsrc + fo));
       const char* const ub_ = reinterpret_cast<const char*>(U);
       const char* const ug_ = reinterpret_cast<const char*>(Ughost);
-      const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(x3) * s_b1 + wave * SPW;
-      const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(x3) * s_b2 + wave * SPW;
+      const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(x3) * s_b1;
+      const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(x3) * s_b2;
       const char* const q1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
       const char* const q2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
       const char* q3;
       bool k_b3 = false;
       if (x3 > 0) q3 = ub_ + ((sw0 - S3) * 4 + 3) * (9 * 16);
       else if (!sp3) q3 = ub_ + ((sw0 + static_cast<int64_t>(L3 - 1) * S3) * 4 + 3) * (9 * 16);
-      else { q3 = ug_ + (static_cast<int64_t>(gm3) + col + wave * SPW) * (9 * 16); k_b3 = true; }
+      else { q3 = ug_ + (static_cast<int64_t>(gm3) + col) * (9 * 16); k_b3 = true; }
 #pragma unroll
       for (int k = 0; k < RBK; ++k)
         if (lane + 64 * k < SPW * 9) {
-          rb1[k] = *reinterpret_cast<const dv2*>(q1 + (k_b1 ? bo_g[k] : bo_f[k]));
-          rb2[k] = *reinterpret_cast<const dv2*>(q2 + (k_b2 ? bo_g[k] : bo_f[k]));
-          rb3[k] = *reinterpret_cast<const dv2*>(q3 + (k_b3 ? bo_g[k] : bo_f[k]));
+          rb1[k] = ld_link(reinterpret_cast<const dv2*>(q1 + (k_b1 ? bo_g[k] : bo_f[k])));
+          rb2[k] = ld_link(reinterpret_cast<const dv2*>(q2 + (k_b2 ? bo_g[k] : bo_f[k])));
+          rb3[k] = ld_link(reinterpret_cast<const dv2*>(q3 + (k_b3 ? bo_g[k] : bo_f[k])));
         }
     };
     auto park_links = [&](int st) __attribute__((always_inline)) {
-      dv2* const Lf = Lw + st * STAGE;
+      dv2* const Lf = Lw + st * LSTAGE;
 #pragma unroll
       for (int k = 0; k < RFW; ++k)
         if (lane + 64 * k < SPW * 36) Lf[36 + lane + 64 * k] = rf[k];
@@ -1585,24 +1567,66 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
           Lf[NFW + 2 * SPW * 9 + lane + 64 * k] = rb3[k];
         }
     };
+    // Row `xs` of this wave's column as stored (slice index, or ring slot), with its two halo sites, `gx3` the slice's true
+    // index (ghost faces keep whole-lattice indexing): pointers of the own sites and, per lane, of the halo site.
+    // kind: 0 a slice of `in`, 1 the +x3 ghost face, 2 the -x3 ghost face (own sites only; no halo is needed from those).
+    auto row_ptrs = [&](int kind, int xs, int gx3, const char*& own, const char*& hal) __attribute__((always_inline)) {
+      if (kind == 0) {
+        own = inb + (static_cast<int64_t>(col) + static_cast<int64_t>(xs) * S3) * RB;
+        const int64_t f0i = x1 + L1 * (x2 + static_cast<int64_t>(L2) * gx3);
+        const char* lft;
+        const char* rgt;
+        if (!row_start) lft = own - RB;
+        else if (!sp0) lft = own + static_cast<int64_t>(L0 - 1) * RB;
+        else lft = ghb + (static_cast<int64_t>(gm0) + f0i) * RB;
+        if (!row_end) rgt = own + static_cast<int64_t>(SPW) * RB;
+        else if (!sp0) rgt = own - static_cast<int64_t>(L0 - SPW) * RB;
+        else rgt = ghb + (static_cast<int64_t>(gp0) + f0i) * RB;
+        hal = (hs ? rgt : lft) + hj * 16;
+      } else {
+        own = ghb + (static_cast<int64_t>(kind == 1 ? gp3 : gm3) + col) * RB;
+        hal = own + hj * 16;  // any valid address: this row is never used as a centre row
+      }
+    };
+    // which stored slice / ghost face is slice g of the column (g may be -1 or L3: periodic image or ghost)
+    auto slice_of = [&](int g, int slot_g, int& kind, int& xs, int& gx3) __attribute__((always_inline)) {
+      if (g >= 0 && g < L3) { kind = 0; xs = RING_IN ? slot_g : g; gx3 = g; }
+      else if (g < 0) {
+        if (!sp3) { kind = 0; xs = RING_IN ? win.ring - 1 : L3 - 1; gx3 = L3 - 1; }
+        else { kind = 2; xs = 0; gx3 = 0; }
+      } else {
+        if (!sp3) { kind = 0; xs = 0; gx3 = 0; }  // slice 0 (ring slot 0: ring | L3)
+        else { kind = 1; xs = 0; gx3 = 0; }
+      }
+    };
+
+    // ---- column prologue: slices x3_lo (centre of the first step) and x3_lo - 1 (its -x3 neighbour) into the row slots
+    __syncthreads();  // every wave has left the previous column (its last step reads both slots)
     int slot = RING ? win.x3_lo % win.ring : 0;
-    int links_in_lds = -1;  // slice whose links sit in the current LDS image
+    {
+      const int lo = win.x3_lo;
+      int kind, xs, gx3;
+      const char* own;
+      const char* hal;
+      slice_of(lo, slot, kind, xs, gx3);
+      row_ptrs(kind, xs, gx3, own, hal);
+      dv2* const Cc = Cbase + ((lo & 1) * NW + wave) * CS;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Cc[co + c * M] = *reinterpret_cast<const dv2*>(own + voff + c * M * 16);
+        if (halo_lane) Cc[ho + c * M] = *reinterpret_cast<const dv2*>(hal + c * M * 16);
+      }
+      slice_of(lo - 1, RING ? (slot == 0 ? win.ring - 1 : slot - 1) : 0, kind, xs, gx3);
+      row_ptrs(kind, xs, gx3, own, hal);
+      dv2* const Cm = Cbase + (((lo + 1) & 1) * NW + wave) * CS;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Cm[co + c * M] = *reinterpret_cast<const dv2*>(own + voff + c * M * 16);
+      fetch_links(lo);
+      park_links(lstage);
+    }
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
       const int step_n = vs0 + x3;
-      if (!wanted(x3)) {  // not this launch's tile: count it as done
-        if (hw.sync != nullptr && lane == 0 && step_n < hw.sync_stride)
-          __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
-        continue;
-      }
-      if (links_in_lds != x3) {  // first tile of a run: fetch and park now, not overlapped
-        fetch_links(x3);
-        park_links(stage);
-        links_in_lds = x3;
-      }
-      int nx = x3 + 1;  // the next tile of this launch in the column: its links are fetched during this one
-      while (CLS != 0 && nx < x3_end && !wanted(nx)) ++nx;
-      if (hw.sync != nullptr && lane == 0 && pace) {  // pacing: all waves of this XCD class within `sync_window` slices
+      if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
         const int need = step_n - hw.sync_window;
         const unsigned known = seen2_idx == need ? seen2 : (seen1_idx == need ? seen1 : 0u);
         if (need >= 0 && known < per) {
@@ -1617,79 +1641,77 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
           }
         }
       }
-      BCG_STAMP(0)  // first-tile link fetch, pacing wait
-      const dv2* const Lf = Lw + stage * STAGE;
+      __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
+      if (x3 + 1 < x3_end) fetch_links(x3 + 1);  // parked at the end of this step
+      const dv2* const Lf = Lw + lstage * LSTAGE;
       const dv2* const Lb = Lf + NFW;
-      // ---- the eight neighbour rows of this tile: scalar pointers
-      const int xf = RING_IN ? slot : x3;                       // where slice x3 of `in` lives
-      const int xfp = RING_IN ? (slot + 1 == win.ring ? 0 : slot + 1) : x3 + 1;
-      const int xfm = RING_IN ? (slot == 0 ? win.ring - 1 : slot - 1) : x3 - 1;
-#define BCG_ROW(A, S, K) ((K) ? ghb + static_cast<int64_t>((A) + x3 * (S)) * RB : inb + static_cast<int64_t>((A) + xf * (S)) * RB)
-      const char* const crow = inb + static_cast<int64_t>(col + xf * S3) * RB;
-      const char* const q_f0 = crow + static_cast<int64_t>(shift_p) * RB;
-      const char* const q_b0 = crow + static_cast<int64_t>(shift_m) * RB;
-      const char* const q_f1 = BCG_ROW(a_f1, s_f1, k_f1);
-      const char* const q_b1 = BCG_ROW(a_b1, s_b1, k_b1);
-      const char* const q_f2 = BCG_ROW(a_f2, s_f2, k_f2);
-      const char* const q_b2 = BCG_ROW(a_b2, s_b2, k_b2);
-#undef BCG_ROW
-      const char* q_f3;
-      const char* q_b3;
-      if (x3 + 1 < L3) q_f3 = inb + static_cast<int64_t>(col + xfp * S3) * RB;
-      else if (!sp3) q_f3 = inb + static_cast<int64_t>(col) * RB;  // slice 0 (slot 0: ring | L3)
-      else q_f3 = ghb + static_cast<int64_t>(gp3 + col) * RB;
-      if (x3 > 0) q_b3 = inb + static_cast<int64_t>(col + xfm * S3) * RB;
-      else if (!sp3) q_b3 = inb + static_cast<int64_t>(col + (RING_IN ? win.ring - 1 : L3 - 1) * S3) * RB;
-      else q_b3 = ghb + static_cast<int64_t>(gm3 + col) * RB;
+      lstage ^= 1;
+      const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;       // centre rows of the four waves (this slice)
+      dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;  // this wave's slot for slice x3 + 1; holds slice x3 - 1
       double2 f[4][3], bk[4][3];
-      const char* const qf[4] = {q_f0, q_f1, q_f2, q_f3};
-      const char* const qb[4] = {q_b0, q_b1, q_b2, q_b3};
-#define BCG_LOAD_DIR(MU)                                                                   \
-  _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                          \
-    f[MU][k] = ld_sv(qf[MU], (MU) == 0 ? voff_p : voff, k * M * 16);                       \
-    bk[MU][k] = ld_sv(qb[MU], (MU) == 0 ? voff_m : voff, k * M * 16);                      \
-  }
-      BCG_LOAD_DIR(0)
-      if (gh0p || gh0m) {  // direction 0 divided over ranks: the edge site of an end-of-row tile reads the ghost face
-        const int64_t f0 = x1 + L1 * (x2 + L2 * x3);
-        if (gh0p && sl == SPB - 1) {
+      // -x3 neighbour: this wave's own row of slice x3 - 1, read back before the slot is overwritten below
 #pragma unroll
-          for (int k = 0; k < 3; ++k) f[0][k] = ghost[(gp0 + f0) * 3 * M + k * M + j];
-        }
-        if (gh0m && sl == 0) {
+      for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; bk[3][c] = make_double2(v.x, v.y); }
+      // ---- global loads of the step: the two rows that leave the bundle, the +x3 row with its halo, p
+      const char* const q_o1 = (k_o1 ? ghb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(x3) * s_o1) * RB
+                                     : inb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(RING_IN ? slot : x3) * s_o1) * RB);
+      const char* const q_o2 = (k_o2 ? ghb + (static_cast<int64_t>(a_o2) + static_cast<int64_t>(x3) * s_o2) * RB
+                                     : inb + (static_cast<int64_t>(a_o2) + static_cast<int64_t>(RING_IN ? slot : x3) * s_o2) * RB);
+      double2 o1[3], o2[3];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) bk[0][k] = ghost[(gm0 + f0) * 3 * M + k * M + j];
-        }
+      for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q_o1, voff, c * M * 16);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
+      dv2 hv[3];
+      {
+        int kind, xs, gx3;
+        const char* own;
+        const char* hal;
+        slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
+        row_ptrs(kind, xs, gx3, own, hal);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[3][c] = ld_sv(own, voff, c * M * 16);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (halo_lane) hv[c] = *reinterpret_cast<const dv2*>(hal + c * M * 16);
       }
       const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
       const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
-      char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col + slot * S3) : crow_site) * RB;
+      char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
       double2 pv[3];
-      seen2 = seen1;
-      seen2_idx = seen1_idx;
-      if (hw.sync != nullptr && lane == 0 && pace && step_n + 2 >= hw.sync_window) {
-        seen1_idx = step_n + 2 - hw.sync_window;
-        seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
+      if (MODE == HOP_SHIFTED) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pv[r] = ld_nt(reinterpret_cast<const double2*>(prow + voff + r * M * 16));
       }
-      BCG_STAMP(1)  // direction-0 loads issued
-      BCG_STAMP(2)
+      // ---- neighbours inside the bundle, from the row slots: x0 (own row shifted by a site), x1 and x2 (partner waves)
+      const dv2* const Cown = Cc + wave * CS;
+      const dv2* const Cp1 = Cc + (wave ^ 1) * CS;
+      const dv2* const Cp2 = Cc + (wave ^ 2) * CS;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const dv2 a = Cown[co + 3 * M + c * M], b = Cown[co - 3 * M + c * M];
+        f[0][c] = make_double2(a.x, a.y);
+        bk[0][c] = make_double2(b.x, b.y);
+      }
+      if (e1) {  // forward row of direction 1 leaves the bundle, backward is the partner's
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = o1[c]; bk[1][c] = make_double2(v.x, v.y); }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = make_double2(v.x, v.y); bk[1][c] = o1[c]; }
+      }
+      if (e2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = o2[c]; bk[2][c] = make_double2(v.x, v.y); }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = make_double2(v.x, v.y); bk[2][c] = o2[c]; }
+      }
       double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-      const int x0 = x0b + sl;
+      const int x0 = x0b + sw;
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
-        if (mu == 0) { BCG_LOAD_DIR(1) }
-        if (mu == 1) { BCG_LOAD_DIR(2) }
-        if (mu == 2) {
-          // Vector memory returns in issue order, so what misses the L2 goes last and together: the new slice (+x3),
-          // p, and the links of the next tile (parked at the end of this one).
-          BCG_LOAD_DIR(3)
-          if (MODE == HOP_SHIFTED) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) pv[r] = ld_nt(reinterpret_cast<const double2*>(prow + voff + r * M * 16));
-          }
-          if (nx < x3_end) fetch_links(nx);
-        }
         __builtin_amdgcn_sched_barrier(0);
         const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
         const double eta = (par & 1) ? -1.0 : 1.0;
@@ -1713,75 +1735,74 @@ __device__ __forceinline__ void hop4w_body(const LatticeDev& lat, const double2*
           acc[r].x = fma(eta, t[r].x, acc[r].x);
           acc[r].y = fma(eta, t[r].y, acc[r].y);
         }
-        // pin this direction's arithmetic here (see the note at the link staging below)
+        // pin this direction's arithmetic here: the compiler otherwise sinks FMAs past the branches below, towards the
+        // stores, and the link entries they read stay live across them
         asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y));
-        BCG_STAMP(3 + mu)  // direction mu: wait for its rows + arithmetic (+ issue of the next direction's loads)
       }
-#undef BCG_LOAD_DIR
+      // Every load of this step has been consumed, so parking the next step's links (an `s_waitcnt vmcnt(0)` in front of
+      // the LDS writes: the compiler cannot count across the step's branches) drains nothing.  The output stores and the
+      // pacing atomics are issued behind it and are never waited for inside the step: k_hop4c parks at the top of the
+      // next tile and drains them there, 13 % of its time.
+      if (x3 + 1 < x3_end) park_links(lstage);
+      // park the +x3 row (own sites and halo) as the next step's centre row
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dv2 v;
+        v.x = f[3][c].x;
+        v.y = f[3][c].y;
+        Cn[co + c * M] = v;
+        if (halo_lane) Cn[ho + c * M] = hv[c];
+      }
       double2 tv[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+        st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
       }
-      // Pin the arithmetic in front of the (lane-predicated, hence branching) link staging below: the compiler otherwise sinks
-      // the FMAs of all four directions past those branches towards the stores, and everything they read -- 72 link
-      // entries -- stays live across them (255 VGPRs spilled).
-      asm volatile("" : "+v"(tv[0].x), "+v"(tv[0].y), "+v"(tv[1].x), "+v"(tv[1].y), "+v"(tv[2].x), "+v"(tv[2].y));
-      __builtin_amdgcn_sched_barrier(0);
-      // every load of this tile has been consumed: parking the next tile's links drains nothing new, and the output
-      // stores issued after it are never waited for inside the loop
-      stage ^= 1;
-      if (nx < x3_end) {
-        park_links(stage);
-        links_in_lds = nx;
-      }
-      __builtin_amdgcn_wave_barrier();  // the next tile's LDS reads (other lanes' writes) stay behind these writes
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
       if (GRAM) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
       }
-      if (hw.sync != nullptr && lane == 0 && step_n < hw.sync_stride)
+      if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
         __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // pacing: read now the counter the tile after next is checked against (see k_hop4)
+      seen2 = seen1;
+      seen2_idx = seen1_idx;
+      if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window) {
+        seen1_idx = step_n + 2 - hw.sync_window;
+        seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
+      }
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
-      BCG_STAMP(7)  // p wait, link parking, stores, Gram step, counter
     }
   }
-#ifdef BCG_HOP4C_STAMPS
-  if (!GRAM && lane == 0) {
-    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 8;
-    for (int i = 0; i < 8; ++i) o[i] = static_cast<double>(seg[i]);
-  }
-#endif
-#undef BCG_STAMP
   if (GRAM) {
     if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
     else gram_block_store<16, NW>(G, smem, partials, tid);
   }
 }
 
-template <int M, int MODE, bool GRAM, int CLS, bool RING>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_hop4w(LatticeDev lat, const double2* __restrict__ U,
-                                               const double2* __restrict__ Ughost, const double2* __restrict__ in,
-                                               const double2* __restrict__ ghost, double2* __restrict__ out,
-                                               const double2* __restrict__ p, double c0,
-                                               double2* __restrict__ partials, HopWalk hw, HopWindow win) {
-  hop4w_body<M, MODE, GRAM, CLS, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
+template <int M, int MODE, bool GRAM, bool RING>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_hop4b(
+    LatticeDev lat, const double2* __restrict__ U, const double2* __restrict__ Ughost, const double2* __restrict__ in,
+    const double2* __restrict__ ghost, double2* __restrict__ out, const double2* __restrict__ p, double c0,
+    double2* __restrict__ partials, HopWalk hw, HopWindow win) {
+  hop4b_body<M, MODE, GRAM, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
 }
 
 #ifdef BCG_PROBE  // tuning aid: compile only the probed stencil instantiations (seconds instead of minutes)
-template __global__ void k_hop4w<16, HOP_PLAIN, false, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
-                                                                  const double2*, double2*, const double2*, double, double2*,
-                                                                  HopWalk, HopWindow);
-template __global__ void k_hop4w<16, HOP_SHIFTED, true, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
-                                                                   const double2*, double2*, const double2*, double, double2*,
-                                                                   HopWalk, HopWindow);
+template __global__ void k_hop4b<16, HOP_PLAIN, false, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                               const double2*, double2*, const double2*, double, double2*,
+                                                               HopWalk, HopWindow);
+template __global__ void k_hop4b<16, HOP_SHIFTED, true, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                                const double2*, double2*, const double2*, double, double2*,
+                                                                HopWalk, HopWindow);
 template __global__ void k_hop4c<16, HOP_PLAIN, false, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
                                                                   const double2*, double2*, const double2*, double, double2*,
                                                                   HopWalk, HopWindow);
+template __global__ void k_hop4c<16, HOP_SHIFTED, true, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
+                                                                   const double2*, double2*, const double2*, double, double2*,
+                                                                   HopWalk, HopWindow);
 }  // namespace
 }  // namespace bcg
 #else
@@ -1994,6 +2015,14 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
   return pl;
 }
 
+// k_hop4b (2 x 2 column bundles) serves whole launches of the column form whose patches are made of whole bundle tiles
+static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const HopPlan& pl, int cls) {
+  const int spw = 64 / m;
+  return pl.valid && pl.column && tune.sync.bundle_walk && cls == 0 && (m != 8 || tune.sync.bundle_walk > 1) &&
+         lat.L[1] % 2 == 0 && lat.L[2] % 2 == 0 && pl.hw.p1 % 2 == 0 && pl.hw.p2 % 2 == 0 && pl.hw.p0 % spw == 0 &&
+         (pl.hw.p0 / spw) * (pl.hw.p1 / 2) * (pl.hw.p2 / 2) == pl.grid / 8;
+}
+
 template <int M>
 static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
                        const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
@@ -2007,30 +2036,32 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   if (pl.list && grid == 0) return 0;  // no boundary tiles
   const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
-  if (pl.column && tune.sync.wave_walk) {  // k_hop4w: the column sweep with independent waves
-    if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
+  // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
+  if (bundle_ok(M, lat, tune, pl, cls)) {
+    HopWalk hwb = hw;  // pacing of the bundle sweep: its own window (default none)
+    if (tune.sync.bundle_window > 0 && hw.sync) hwb.sync_window = tune.sync.bundle_window;
+    else hwb.sync = nullptr;
+    if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
     constexpr int SPW = 64 / M;
-    const size_t lds_u = sizeof(double2) * 4 * 2 * ((SPW + 1) * 36 + 3 * SPW * 9);
+    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPW + 2) * 3 * M) + 4 * 2 * ((SPW + 1) * 36 + 3 * SPW * 9));
     const size_t lds = lds_u > lds_g ? lds_u : lds_g;
-#define BCG_LAUNCH4W(MM, MD, GR, CL, RG)                                                                                \
-  do {                                                                                                                 \
-    allow_lds(k_hop4w<MM, MD, GR, CL, RG>, lds);                                                                       \
-    hipLaunchKernelGGL((k_hop4w<MM, MD, GR, CL, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
-                       c0, partials, hw, win);                                                                         \
+#define BCG_LAUNCH4B(MM, MD, GR, RG)                                                                                \
+  do {                                                                                                             \
+    allow_lds(k_hop4b<MM, MD, GR, RG>, lds);                                                                       \
+    hipLaunchKernelGGL((k_hop4b<MM, MD, GR, RG>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                       c0, partials, hwb, win);                                                                     \
   } while (0)
-#define BCG_LAUNCH4W_R(MM, MD, GR)                          \
-  do {                                                      \
-    if (win.ring > 0) BCG_LAUNCH4W(MM, MD, GR, 0, true);    \
-    else if (cls == 1) BCG_LAUNCH4W(MM, MD, GR, 1, false);  \
-    else if (cls == 2) BCG_LAUNCH4W(MM, MD, GR, 2, false);  \
-    else BCG_LAUNCH4W(MM, MD, GR, 0, false);                \
+#define BCG_LAUNCH4B_R(MM, MD, GR)                      \
+  do {                                                  \
+    if (win.ring > 0) BCG_LAUNCH4B(MM, MD, GR, true);   \
+    else BCG_LAUNCH4B(MM, MD, GR, false);               \
   } while (0)
-    if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4W_R(16, HOP_SHIFTED, true);
-    else if (gram && M == 8 && mode == HOP_SHIFTED) BCG_LAUNCH4W_R(8, HOP_SHIFTED, true);
-    else if (mode == HOP_PLAIN) BCG_LAUNCH4W_R(M, HOP_PLAIN, false);
-    else BCG_LAUNCH4W_R(M, HOP_SHIFTED, false);
-#undef BCG_LAUNCH4W_R
-#undef BCG_LAUNCH4W
+    if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4B_R(16, HOP_SHIFTED, true);
+    else if (gram && M == 8 && mode == HOP_SHIFTED) BCG_LAUNCH4B_R(8, HOP_SHIFTED, true);
+    else if (mode == HOP_PLAIN) BCG_LAUNCH4B_R(M, HOP_PLAIN, false);
+    else BCG_LAUNCH4B_R(M, HOP_SHIFTED, false);
+#undef BCG_LAUNCH4B_R
+#undef BCG_LAUNCH4B
     return grid;
   }
   if (pl.column) {
@@ -2092,6 +2123,12 @@ int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTunin
   const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
   const HopPlan pl = plan_hop4(m, lat, mb, tune, tile_class, win);
   return !pl.valid ? -1 : (pl.column ? 2 : 1);
+}
+
+bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win) {
+  if (!hop_can_split_tiles(m, lat)) return false;
+  const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
+  return bundle_ok(m, lat, tune, plan_hop4(m, lat, mb, tune, tile_class, win), tile_class);
 }
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,

@@ -54,8 +54,8 @@ RING_CASES = [
 
 
 COLUMN_CASES = [
-    # local lattice 32x8x8x6 (m = 16) with 32 blocks and 16x2x2 patches: the column-sweep kernel (k_hop4c) with ghost faces
-    # in every direction; the exchange is not split, so the whole stencil is one launch
+    # local lattice 32x8x8x6 (m = 16) with 32 blocks and 16x2x2 patches: the column sweep with ghost faces in every direction
+    # -- as one launch over 2 x 2 column bundles (k_hop4b, "whole") and as the interior + boundary classes of k_hop4c
     ([64, 8, 8, 6], [2, 1, 1, 1], 16, 0),     # x0 divided: edge lanes patched from the ghost face, U_0 ghost
     ([32, 16, 8, 6], [1, 2, 1, 1], 16, 0),    # x1
     ([32, 8, 16, 12], [1, 1, 2, 2], 16, 0),   # x2 and x3, 4 ranks

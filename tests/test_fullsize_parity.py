@@ -1,5 +1,6 @@
 """Parity of the PRODUCTION launch geometry at BASELINE.json's full per-GPU shapes (default tuning: no BCG_HOP_*
-overrides, so 64^4 runs k_hop4c with 512 blocks, 16x8x8 patches and XCD pacing, exactly what bench.py times).
+overrides, so 64^4 runs the bundle sweep k_hop4b with 512 blocks over 16x8x8 patches -- k_hop4c for the tile classes --
+exactly what bench.py times).
 
 Two independent checks, both against the CPU oracle, neither needs a lattice-sized host computation:
 
