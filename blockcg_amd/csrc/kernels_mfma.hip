@@ -237,29 +237,31 @@ __device__ __forceinline__ void gram_step(GramAcc<M>& G, const double2* a, const
 // red: LDS scratch of NW * JB*JB * 2 * 4 * 64 doubles.
 template <int M, int NW>
 __device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* red, double2* __restrict__ partials, int tid) {
+  // one 16 x 16 block of the Gram matrix at a time through a buffer of NW * 8 * 64 doubles (16 KB at four waves): at
+  // m = 32 a buffer for all four blocks was 64 KB and left phase B a single block per CU
   constexpr int JB = M / 16;
-  constexpr int FR = JB * JB * 2 * 4;  // doubles per lane
   const int wave = tid >> 6, lane = tid & 63;
-  __syncthreads();
 #pragma unroll
-  for (int q = 0; q < JB * JB; ++q)
+  for (int q = 0; q < JB * JB; ++q) {
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      red[((wave * FR) + (q * 8 + r)) * 64 + lane] = G.re[q][r];
-      red[((wave * FR) + (q * 8 + 4 + r)) * 64 + lane] = G.im[q][r];
+      red[(wave * 8 + r) * 64 + lane] = G.re[q][r];
+      red[(wave * 8 + 4 + r) * 64 + lane] = G.im[q][r];
     }
-  __syncthreads();
-  // element e = (q, r, lane): i = 16*ja + (lane>>4) + 4r, j = 16*jb + (lane&15)
-  for (int e = tid; e < JB * JB * 4 * 64; e += NW * 64) {
-    const int l = e & 63, r = (e >> 6) & 3, q = e >> 8;
-    double sr = 0.0, si = 0.0;
+    __syncthreads();
+    // element e = (r, lane): i = 16*ja + (lane>>4) + 4r, j = 16*jb + (lane&15)
+    for (int e = tid; e < 4 * 64; e += NW * 64) {
+      const int l = e & 63, r = (e >> 6) & 3;
+      double sr = 0.0, si = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      sr += red[((w * FR) + (q * 8 + r)) * 64 + l];
-      si += red[((w * FR) + (q * 8 + 4 + r)) * 64 + l];
+      for (int w = 0; w < NW; ++w) {
+        sr += red[(w * 8 + r) * 64 + l];
+        si += red[(w * 8 + 4 + r) * 64 + l];
+      }
+      const int i = 16 * (q / JB) + (l >> 4) + 4 * r, j = 16 * (q % JB) + (l & 15);
+      partials[static_cast<int64_t>(blockIdx.x) * (M * M) + j * M + i] = make_double2(sr, si);
     }
-    const int i = 16 * (q / JB) + (l >> 4) + 4 * r, j = 16 * (q % JB) + (l & 15);
-    partials[static_cast<int64_t>(blockIdx.x) * (M * M) + j * M + i] = make_double2(sr, si);
   }
 }
 
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
   constexpr int NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row (M*16 + 16 bytes)
   constexpr int JB = M / 16;
-  constexpr int RED = NW * JB * JB * 8 * 64;
+  constexpr int RED = NW * 8 * 64;
   constexpr int TRN = NW * 16 * TLD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ml = smem;                                   // MatLds<M>::DOUBLES
@@ -354,10 +356,11 @@ struct ShiftPtrs {
 
 // PREFETCH: load the next shift's P/X tiles while the current shift's MFMAs run (m = 16).  At m = 32 a tile is
 // 32 VGPRs, the prefetch would push the kernel to one wave per SIMD, and one launch takes a single shift anyway.
-template <int M, bool PREFETCH>
-__global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
-                                                const double2* __restrict__ mats, int apply_rinv) {
-  constexpr int NW = 4;
+// NW: waves per block.  At m = 32 a coefficient matrix is 16.6 KB of LDS; one block of 8 waves per CU (instead of two
+// of 4) shares 9 matrices -- Rinv and four shifts -- so that 8 shifts are two launches and Q is read twice, not five times.
+template <int M, bool PREFETCH, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
+                                                    const double2* __restrict__ mats, int apply_rinv) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(256) k_phaseC(int64_t rows, double2* __restric
   // matrix is 16.6 KB: without it a launch that does not apply Rinv fits two shifts at two blocks per CU)
   const int off = apply_rinv ? 0 : 1;
   const int nmat = 1 + 2 * nshift - off;
-  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k + off) * M * M, tid, 256);
+  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k + off) * M * M, tid, NW * 64);
   __syncthreads();
   const double* const smat = smem - off * MD;  // slot of mats[i] = smat + i * MD
   const int r = lane & 15, kq = lane >> 4;
@@ -1886,7 +1889,10 @@ bool hop_can_split_tiles(int m, const LatticeDev& lat) {
   return hop_fast_width(m) && lat.ndim == 4 && lat.L[0] % spb == 0 && lat.V < (int64_t(1) << 31) - 2 * lat.stride[3];
 }
 bool mfma_rows_width(int m) { return m == 8 || m == 16 || m == 32; }  // right-multiply kernels (phase C, K5, K6)
-int phaseC_max_shifts(int m, bool applies_rinv) { return (m == 16 || m == 8) ? 8 : (m == 32 ? (applies_rinv ? 1 : 2) : 0); }
+int phaseC_max_shifts(int m, bool applies_rinv) {
+  (void)applies_rinv;  // m = 32: 9 matrices (Rinv + 4 shifts) are 149.8 KB of the 160 KB of a CU, one 8-wave block each
+  return (m == 16 || m == 8) ? 8 : (m == 32 ? 4 : 0);
+}
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
                   double2* partials, int max_blocks) {
@@ -1900,7 +1906,7 @@ int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2*
     hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
   } else {
     constexpr int M = 32;
-    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 4 * 8 * 64);  // RED 8192 >= TRN 4*16*66
+    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * 66);  // TRN 4224 >= RED 2048: 50 KB, 3 blocks per CU
     allow_lds(k_phaseB<M>, lds);
     hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
   }
@@ -1928,8 +1934,14 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
-    allow_lds(k_phaseC<M, false>, lds);
-    hipLaunchKernelGGL((k_phaseC<M, false>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    if (nmat > 4) {  // more matrices than two 4-wave blocks per CU can hold: one 8-wave block per CU
+      const int grid8 = grid_tiles((rows + 15) / 16, 8, max_blocks / 4 > 0 ? max_blocks / 4 : 1);  // one resident block per CU
+      allow_lds(k_phaseC<M, true, 8>, lds);  // 2 waves per SIMD whatever the registers (LDS-bound): room for the tile prefetch
+      hipLaunchKernelGGL((k_phaseC<M, true, 8>), dim3(grid8), dim3(512), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    } else {
+      allow_lds(k_phaseC<M, false>, lds);
+      hipLaunchKernelGGL((k_phaseC<M, false>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    }
   }
 }
 
@@ -1958,8 +1970,7 @@ int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const
     const size_t lds = sizeof(double) * 4 * 8 * 64;
     hipLaunchKernelGGL((k_gram_mfma<16>), dim3(grid), dim3(256), lds, s, rows, a, b, partials);
   } else {
-    const size_t lds = sizeof(double) * 4 * 4 * 8 * 64;
-    allow_lds(k_gram_mfma<32>, lds);
+    const size_t lds = sizeof(double) * 4 * 8 * 64;
     hipLaunchKernelGGL((k_gram_mfma<32>), dim3(grid), dim3(256), lds, s, rows, a, b, partials);
   }
   return grid;
