@@ -25,7 +25,7 @@ _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_dbl_p = ctypes.POINTER(ctypes.c_double)
 
 SUPPORTED_M = (1, 2, 3, 4, 6, 8, 12, 16, 32)
-REF_SUPPORTED_M = (1, 2, 3, 4, 8, 12, 16)
+REF_SUPPORTED_M = (1, 2, 3, 4, 6, 8, 12, 16, 32)
 
 
 def build(ref=None):

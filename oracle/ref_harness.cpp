@@ -120,9 +120,11 @@ void store_mat(const block_matrix<N>& m, double* p) {
     case 2: { constexpr int N = 2; CALL; } break;  \
     case 3: { constexpr int N = 3; CALL; } break;  \
     case 4: { constexpr int N = 4; CALL; } break;  \
+    case 6: { constexpr int N = 6; CALL; } break;  \
     case 8: { constexpr int N = 8; CALL; } break;  \
     case 12: { constexpr int N = 12; CALL; } break; \
     case 16: { constexpr int N = 16; CALL; } break; \
+    case 32: { constexpr int N = 32; CALL; } break; \
     default: return -1;                            \
   }
 }  // namespace

@@ -138,6 +138,10 @@ def main():
     gen_nd("ref4d_4x4x2x2_m16.npz", [4, 4, 2, 2], 16, 0.2, s4, 1e-10, 1e-12, 12, early=2)
     gen_nd("ref4d_6x4x4x2_m8.npz", [6, 4, 4, 2], 8, 0.1, [0.0], 1e-10, 1e-12, 13, early=2)
     gen_nd("ref4d_8x8x8x8_m4.npz", [8, 8, 8, 8], 4, 0.05, s4, 1e-10, 1e-10, 14, early=0, full=False)
+    # the widest MFMA path (BASELINE config 4: m = 32, 8 shifts) and the one generic width without a fixture so far
+    s8 = sorted([0.0, 1e-6, 1e-4, 1e-2, 1e-5, 1e-3, 1e-1, 1.0])
+    gen_nd("ref4d_4x2x2x4_m32.npz", [4, 2, 2, 4], 32, 0.3, s8, 1e-10, 1e-12, 15, early=1)
+    gen_1d("ref1d_v64_m6.npz", 64, 6, 0.4, [0.0, 0.05], 1e-10, 1e-15, 2, early=2)
     gen_other_solvers("ref1d_v128_other_solvers.npz")
 
 
