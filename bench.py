@@ -112,6 +112,7 @@ def main():
                          "(default: 0 on one GPU, 8 on several with the default shape)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    default_shape = args.local_dims is None and args.capacity is None
     args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity)
 
     import torch
@@ -241,7 +242,7 @@ def main():
             "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
                                    f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)"
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
-                                      "(64^3x128 per GPU, capacity ring 8)" if headline_ladder or world == 1 else ""),
+                                      "(64^3x128 per GPU, capacity ring 8)" if default_shape else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
             "iterations_per_sec": its,
             "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,

@@ -1226,12 +1226,35 @@ int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_fiel
   if (!c || !g || !X || !B || !sigma || !res_out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
   const int m = B->m;
   FieldPool pool(c);
-  bcg_field* AX;
-  BCG_TRY(pool.make(m, &AX));
+  bcg_field* AX = nullptr;  // only the unfused path needs it
   CMat b2, r2;
   BCG_TRY(gram(c, B, B, b2));
   for (int s = 0; s < n_shifts; ++s) {
     if (!same_shape(X[s], B)) return BCG_ERR_INVALID;
+    // One pass where the bundle stencil applies (m = 16, whole-field tmp): tmp = D X_s, then the second stencil
+    // forms (mass^2 + sigma_s) X_s - D tmp - B in registers and accumulates its Gram product; AX is never written
+    // (5 field passes + 2 link passes instead of 9 + 2).
+    if (m == 16 && fast_hop(c, m) && !capacity_path(c, m) &&
+        bcg::hop_uses_bundle(m, c->lat, kFastBlocks, c->hop_tune, 0, bcg::HopWindow())) {
+      bcg_field* tmp;
+      BCG_TRY(get_tmp(c, m, &tmp));
+      BCG_TRY(hop(c, g, tmp, X[s], bcg::HOP_PLAIN, nullptr, 0.0));
+      BCG_TRY(halo_field(c, tmp));
+      BCG_TRY(ensure_scratch(c));
+      int nb;
+      {
+        ProfScope ps(c, "hop_residual");
+        nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, tmp->d, c->halo_recv, const_cast<double2*>(B->d),
+                                  bcg::HOP_RESID, X[s]->d, mass * mass + sigma[s], c->partials, true, kFastBlocks, c->hop_tune, 0);
+      }
+      if (nb > 0) {
+        BCG_TRY(check_launch(c, "hop_residual"));
+        BCG_TRY(finish_gram(c, m, nb, r2, true));
+        for (int i = 0; i < m; ++i) res_out[s * m + i] = std::sqrt(r2(i, i).real() / b2(i, i).real());
+        continue;
+      }
+    }
+    if (!AX) BCG_TRY(pool.make(m, &AX));
     BCG_TRY(apply_shifted(c, g, mass, sigma[s], AX, X[s]));  // op + add(X_s, sigma_s) in one pass
     BCG_TRY(axpby(c, AX, 1.0, B, -1.0, "axpby"));
     BCG_TRY(gram(c, AX, AX, r2));
@@ -1310,18 +1333,26 @@ int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* co
     BCG_TRY(real_dot(c, r, r, rr));                         // :69
     const double beta_old = beta;
     beta = rr / rr_old;                                     // :71
-    BCG_TRY(axpby(c, x[0], 1.0, p[0], alpha, "axpby"));     // :73
-    BCG_TRY(axpby(c, p[0], beta, r, 1.0, "axpby"));         // :75
+    // :73-87 -- the updates of all active shifts as ONE pass over r, x_s, p_s (k_scg_update; same expressions as the
+    // axpys, so the same iterates): coefficients first, then one launch
+    std::vector<double> a_s(active), b_s(active), z_s(active);
+    std::vector<double2*> xs(active), ps(active);
+    a_s[0] = alpha; b_s[0] = beta; z_s[0] = 1.0;            // :73, :75
     for (int s = active - 1; s > 0; --s) {                  // :76
       double inv_theta = 1.0 + (sigma[s] - sigma[0]) * alpha;              // :78
       inv_theta += beta_old * (alpha / alpha_old) * (1.0 - theta[s]);      // :79
       theta[s] = 1.0 / inv_theta;                                          // :80
       zeta[s] *= theta[s];                                                 // :81
-      const double alpha_s = alpha * theta[s];                             // :82
-      const double beta_s = beta * theta[s] * theta[s];                    // :83
-      BCG_TRY(axpby(c, x[s], 1.0, p[s], alpha_s, "axpby"));                // :85
-      BCG_TRY(axpby(c, p[s], beta_s, r, zeta[s], "axpby"));                // :87
+      a_s[s] = alpha * theta[s];                                           // :82  x_s += alpha_s p_s  (:85)
+      b_s[s] = beta * theta[s] * theta[s];                                 // :83  p_s = beta_s p_s + zeta_s r  (:87)
+      z_s[s] = zeta[s];
     }
+    for (int s = 0; s < active; ++s) { xs[s] = x[s]->d; ps[s] = p[s]->d; }
+    {
+      ProfScope ps_(c, "scg_update");
+      bcg::launch_scg_update(c->stream, r->d, active, xs.data(), ps.data(), a_s.data(), b_s.data(), z_s.data(), rows_of(c));
+    }
+    BCG_TRY(check_launch(c, "scg_update"));
     if (std::sqrt(rr) * zeta[active - 1] < eps_shifts) --active;           // :90-92
   }
   BCG_TRY(stream_sync(c));

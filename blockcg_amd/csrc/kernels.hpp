@@ -31,6 +31,9 @@ bool mfma_width(int m);  // widths with an MFMA fast path
 // ---- elementwise / layout --------------------------------------------------------------------
 // y = a*y + b*x over n complex elements (K2, K3, K9, operator+=)
 void launch_axpby(hipStream_t s, double2* y, double a, const double2* x, double b, int64_t n);
+// SCG: x_s += alpha_s p_s ; p_s = beta_s p_s + zeta_s r for all listed shifts in one pass (bit-identical to the axpys)
+void launch_scg_update(hipStream_t s, const double2* r, int nshift, double2* const* x, double2* const* p,
+                       const double* alpha, const double* beta, const double* zeta, int64_t n);
 void launch_host_to_dev(hipStream_t s, int m, const double2* host_layout, double2* dev_layout, int64_t nsites);
 void launch_dev_to_host(hipStream_t s, int m, const double2* dev_layout, double2* host_layout, int64_t nsites);
 void launch_fill_field(hipStream_t s, int m, const LatticeDev& lat, const int* gdims, double2* f, uint64_t seed);
@@ -47,9 +50,12 @@ void launch_pack_faces(hipStream_t s, int m, const LatticeDev& lat, const double
 void launch_pack_gauge_faces(hipStream_t s, const LatticeDev& lat, const double2* U, double2* send);
 
 // ---- generic (any supported m) kernels ---------------------------------------------------------
-enum HopMode { HOP_PLAIN = 0, HOP_SHIFTED = 1 };
+enum HopMode { HOP_PLAIN = 0, HOP_SHIFTED = 1, HOP_RESID = 2 };
 // HOP_PLAIN  : out = D in                          (K1, inc/dirac_op.hpp:14-21)
 // HOP_SHIFTED: out = c0 * p - D in                 (second D of op fused with K2 and K3)
+// HOP_RESID  : nothing is written; r = c0 * p - D in - b with b passed in `out`'s place, and the block partials of
+//              r^dagger r are left like a fused Gram product (the reference's residual check, test/solvers.cpp:105-111,
+//              as one pass; specialised bundle kernel at m = 16 only, launch_hop_fast returns -1 otherwise)
 void launch_hop_generic(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,
                         const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p,
                         double c0);

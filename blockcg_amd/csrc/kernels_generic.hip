@@ -120,6 +120,27 @@ __global__ void k_axpby(double2* __restrict__ y, double a, const double2* __rest
   }
 }
 
+// SCG's per-shift updates of one iteration (src/standard_solvers.cpp:73-75,85-87) as one pass: r is read once, every x_s
+// and p_s once, instead of three passes per axpy (1 + 4 S field passes instead of 6 S).  The expressions are k_axpby's, so
+// the iterates are those of the unfused sequence:  x_s += alpha_s p_s ;  p_s = beta_s p_s + zeta_s r.
+struct ScgShiftArgs {
+  double2* x[16];
+  double2* p[16];
+  double alpha[16], beta[16], zeta[16];
+  double one;  // 1.0 at run time: keeps the expression (and its FMA contraction) the one k_axpby compiles to
+};
+__global__ void k_scg_update(const double2* __restrict__ r, ScgShiftArgs a, int nshift, int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const double2 rv = r[i];
+    for (int s = 0; s < nshift; ++s) {
+      const double2 pv = a.p[s][i], xv = a.x[s][i];
+      a.x[s][i] = make_double2(a.one * xv.x + a.alpha[s] * pv.x, a.one * xv.y + a.alpha[s] * pv.y);
+      a.p[s][i] = make_double2(a.beta[s] * pv.x + a.zeta[s] * rv.x, a.beta[s] * pv.y + a.zeta[s] * rv.y);
+    }
+  }
+}
+
 // dev[(site*3+c)*m + j] = host[(site*m + j)*3 + c]
 __global__ void k_host_to_dev(int m, const double2* __restrict__ h, double2* __restrict__ d, int64_t n) {
   const int row = 3 * m;
@@ -500,6 +521,22 @@ bool width_supported(int m) {
 
 void launch_axpby(hipStream_t s, double2* y, double a, const double2* x, double b, int64_t n) {
   hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, y, a, x, b, n);
+}
+void launch_scg_update(hipStream_t s, const double2* r, int nshift, double2* const* x, double2* const* p,
+                       const double* alpha, const double* beta, const double* zeta, int64_t n) {
+  for (int s0 = 0; s0 < nshift; s0 += 16) {  // 16 shifts per launch (kernel-argument space)
+    ScgShiftArgs a{};
+    a.one = 1.0;
+    const int ns = nshift - s0 < 16 ? nshift - s0 : 16;
+    for (int k = 0; k < ns; ++k) {
+      a.x[k] = x[s0 + k];
+      a.p[k] = p[s0 + k];
+      a.alpha[k] = alpha[s0 + k];
+      a.beta[k] = beta[s0 + k];
+      a.zeta[k] = zeta[s0 + k];
+    }
+    hipLaunchKernelGGL(k_scg_update, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, r, a, ns, n);
+  }
 }
 void launch_host_to_dev(hipStream_t s, int m, const double2* h, double2* d, int64_t nsites) {
   const int64_t n = nsites * 3 * m;

@@ -1429,6 +1429,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   static_assert(!GRAM || M == 16 || M == 8, "fused Gram accumulation: lane&15 = rhs index (m = 16) or (site parity, rhs) (m = 8)");
   constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
+  constexpr bool RESID = MODE == HOP_RESID;  // no output: the Gram product of (c0 p - D in - b) with itself, b passed as `out`
+  static_assert(!RESID || (GRAM && !RING), "the residual form accumulates a Gram product and is not ring-addressed");
   constexpr int SPW = 64 / M;              // sites per wave = tile extent in x0
   constexpr int NW = 4;
   constexpr int CS = (SPW + 2) * 3 * M;    // one wave's row slot: halo site, SPW sites, halo site (complex numbers)
@@ -1681,10 +1683,14 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
       const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
       char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
-      double2 pv[3];
-      if (MODE == HOP_SHIFTED) {
+      double2 pv[3], bv[3];
+      if (MODE != HOP_PLAIN) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) pv[r] = ld_nt(reinterpret_cast<const double2*>(prow + voff + r * M * 16));
+      }
+      if (RESID) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) bv[r] = ld_nt(reinterpret_cast<const double2*>(orow + voff + r * M * 16));
       }
       // ---- neighbours inside the bundle, from the row slots: x0 (own row shifted by a site), x1 and x2 (partner waves)
       const dv2* const Cown = Cc + wave * CS;
@@ -1761,11 +1767,12 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       for (int r = 0; r < 3; ++r) {
         if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-        st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+        if (RESID) tv[r] = make_double2(tv[r].x - bv[r].x, tv[r].y - bv[r].y);  // AX -= B (test/solvers.cpp:109)
+        else st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
       }
       if (GRAM) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
+        for (int r = 0; r < 3; ++r) gram_step<16>(G, RESID ? &tv[r] : &pv[r], &tv[r]);
       }
       if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
         __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2067,7 +2074,10 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
     if (win.ring > 0) BCG_LAUNCH4B(MM, MD, GR, true);   \
     else BCG_LAUNCH4B(MM, MD, GR, false);               \
   } while (0)
-    if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4B_R(16, HOP_SHIFTED, true);
+    if (mode == HOP_RESID) {
+      if (M != 16 || !gram || win.ring > 0) return -1;
+      BCG_LAUNCH4B(16, HOP_RESID, true, false);
+    } else if (gram && M == 16 && mode == HOP_SHIFTED) BCG_LAUNCH4B_R(16, HOP_SHIFTED, true);
     else if (gram && M == 8 && mode == HOP_SHIFTED) BCG_LAUNCH4B_R(8, HOP_SHIFTED, true);
     else if (mode == HOP_PLAIN) BCG_LAUNCH4B_R(M, HOP_PLAIN, false);
     else BCG_LAUNCH4B_R(M, HOP_SHIFTED, false);
@@ -2075,6 +2085,7 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
 #undef BCG_LAUNCH4B
     return grid;
   }
+  if (mode == HOP_RESID) return -1;  // the fused residual form exists in the bundle sweep only
   if (pl.column) {
     if (hw.sync) (void)hipMemsetAsync(hw.sync, 0, sizeof(unsigned) * 8 * hw.sync_stride, s);
     const size_t lds_u = sizeof(double2) * 2 * ((SPB + 1) * 36 + 3 * SPB * 9);
@@ -2154,7 +2165,7 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
     if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
     return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
   }
-  if (win.x3_n > 0 || win.ring > 0) return -1;  // x3 windows and ring addressing exist in the specialised kernel only
+  if (win.x3_n > 0 || win.ring > 0 || mode == HOP_RESID) return -1;  // specialised kernel only
   if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles
   const int64_t ntiles = (lat.V + spb - 1) / spb;
   const int grid = grid_tiles(ntiles, 1, max_blocks);

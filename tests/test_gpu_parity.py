@@ -554,3 +554,29 @@ def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, bundle, mon
         want, other = ("stencil_form_k_hop4b", "stencil_form_k_hop4c") if bundle != "0" else ("stencil_form_k_hop4c", "stencil_form_k_hop4b")
         assert prof.get(want, {}).get("count", 0) > 0 and other not in prof, prof.keys()
         assert "stencil_form_k_hop4" not in prof and "stencil_form_general" not in prof
+
+
+def test_fused_true_residual_check(bc, orc, monkeypatch):
+    """bcg_true_residuals (test/solvers.cpp:104-116, benchmark.cpp:93-103) in its one-pass form -- second stencil, `-= B`
+    and the Gram product fused in the bundle kernel, AX never written (m = 16) -- against the oracle and against the unfused
+    sequence of primitives, on unconverged iterates so that the residuals are O(1e-2)."""
+    dims, m, mass, shifts = [16, 8, 8, 8], 16, 0.2, [0.0, 0.01, 0.3]
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 91)
+    Bh = orc.fill_field(m, V, 92)
+    got = {}
+    for bundle in ("1", "0"):
+        monkeypatch.setenv("BCG_HOP_BUNDLE", bundle)
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=6)
+        got[bundle] = (bc.true_residuals(X, B, D, shifts), np.stack([x.download() for x in X]), ctx.profile())
+    assert got["1"][2].get("hop_residual", {}).get("count", 0) == len(shifts)   # the fused form ran ...
+    assert "hop_residual" not in got["0"][2]                                      # ... and the primitives' form here
+    want = orc.true_residuals(U, dims, mass, Bh, shifts, got["1"][1])
+    assert 1e-6 < want.max() < 1.0
+    assert rel_err(got["1"][0], want) < 1e-11
+    assert rel_err(got["0"][0], want) < 1e-11
