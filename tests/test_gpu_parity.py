@@ -561,6 +561,8 @@ def test_fused_true_residual_check(bc, orc, monkeypatch):
     and the Gram product fused in the bundle kernel, AX never written (m = 16) -- against the oracle and against the unfused
     sequence of primitives, on unconverged iterates so that the residuals are O(1e-2)."""
     dims, m, mass, shifts = [16, 8, 8, 8], 16, 0.2, [0.0, 0.01, 0.3]
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")  # a lattice this small needs small patches for the column / bundle sweep
+    monkeypatch.setenv("BCG_HOP_BLOCKS", "32")
     V = int(np.prod(dims))
     U = orc.fill_gauge(dims, 91)
     Bh = orc.fill_field(m, V, 92)
