@@ -1,6 +1,10 @@
 // libblockcg_rccl.so: bcg_comm on RCCL (include/blockcg_rccl.h).  Host code only; the transfers are RCCL's kernels.
 #include <hip/hip_runtime.h>
+#ifdef BCG_RCCL_MOCK  // tests only: several ranks on ONE GPU (tests/cpp/mock_rccl.hpp); never part of libblockcg_rccl.so
+#include "../../tests/cpp/mock_rccl.hpp"
+#else
 #include <rccl/rccl.h>
+#endif
 #include <unistd.h>
 
 #include <chrono>

@@ -8,7 +8,10 @@ import os
 
 from . import _lib
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libblockcg_rccl.so")
+# BCG_RCCL_LIB: another build of the transport -- the tests use libblockcg_rccl_mock.so (the same comm_rccl.cpp over a
+# host-staged stand-in for RCCL) to run several ranks of the NATIVE callbacks on one GPU
+LIB_PATH = os.environ.get("BCG_RCCL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build",
+                                                          "libblockcg_rccl.so")
 UNIQUE_ID_BYTES = 128
 
 SIGNATURES = {

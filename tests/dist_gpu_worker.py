@@ -27,9 +27,22 @@ def main():
     assert int(np.prod(grid)) == world
     nd = len(gdims)
     coords = coords_of(rank, grid)
-    comm = TorchDistComm(0, overlap=os.environ.get("BCG_TEST_OVERLAP", "1") == "1")
-    ctx = bc.Context(gdims, device=0, grid=grid, coords=coords, stream=comm.stream_ptr)
-    comm.attach(ctx)
+    if os.environ.get("BCG_TEST_TRANSPORT", "torch") == "native":
+        # the native transport (libblockcg_rccl*.so; BCG_RCCL_LIB selects the host-staged twin for ranks sharing a GPU)
+        from blockcg_amd import rccl
+        uid = [rccl.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx = bc.Context(gdims, device=0, grid=grid, coords=coords)
+        comm = rccl.RcclComm(ctx, uid[0], rank, world)
+        if os.environ.get("BCG_TEST_OVERLAP", "1") != "1":  # blocking exchange only: drop the split callbacks
+            cb = comm.callbacks
+            from blockcg_amd import _lib
+            blocking = _lib.bcg_comm(cb.user, cb.halo_exchange, cb.allreduce_sum, _lib.HALO_CB(), _lib.HALO_END_CB())
+            ctx.set_comm(blocking, comm)
+    else:
+        comm = TorchDistComm(0, overlap=os.environ.get("BCG_TEST_OVERLAP", "1") == "1")
+        ctx = bc.Context(gdims, device=0, grid=grid, coords=coords, stream=comm.stream_ptr)
+        comm.attach(ctx)
     ctx.force_generic(generic)
     ctx.capacity_mode(int(os.environ.get("BCG_TEST_RING", "0")))
     mass, shifts, iters = 0.1, [0.0, 1e-3, 1e-1], 4

@@ -24,13 +24,24 @@ CASES = [
 ]
 
 
-def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True):
+def _mock_transport():
+    """libblockcg_rccl_mock.so: the native transport (blockcg_amd/csrc/comm_rccl.cpp, unchanged) over a host-staged stand-in
+    for the seven RCCL calls it makes (tests/cpp/mock_rccl.hpp), so that its ranks can share the one GPU of a test box."""
+    lib = os.path.join(ROOT, "blockcg_amd", "_build", "libblockcg_rccl_mock.so")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "blockcg_amd", "csrc"), "-s", "mock"], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(lib), r.stderr[-2000:]
+    return lib
+
+
+def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False):
     world = 1
     for g in grid:
         world *= g
     env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)),
                BCG_TEST_M=str(m), BCG_TEST_GENERIC="1" if generic else "0", BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1",
                BCG_HOP_BLOCKS=blocks, BCG_HOP_PATCH=patch, BCG_TEST_OVERLAP="1" if overlap else "0")
+    if native:
+        env.update(BCG_TEST_TRANSPORT="native", BCG_RCCL_LIB=_mock_transport())
     port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
@@ -133,3 +144,39 @@ def test_bench_two_ranks_on_one_gpu():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["global_dims"] == [16, 16, 16, 32]
+
+
+def test_bench_ranks_on_one_gpu_native_transport():
+    """bench.py's default transport path (BCG_BACKEND=rccl: unique id over the gloo control plane, blockcg_amd.rccl.RcclComm,
+    capacity ring, x3 undivided process grid) with 4 ranks on GPU 0 over the host-staged stand-in."""
+    env = dict(os.environ, BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1",
+               BCG_HOP_BLOCKS="32", BCG_HOP_PATCH="16,2,2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+           "--local-dims", "32", "8", "8", "8", "--capacity", "4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["transport"] == "rccl" and d["capacity_ring_slices"] == 4
+    assert d["config"]["process_grid"] == [1, 2, 2, 1] and d["config"]["global_dims"] == [32, 16, 16, 8] and d["value"] > 0
+
+
+NATIVE_CASES = [
+    # dims,             grid,          m,  ring, overlap (split exchange: second stream + events), blocks
+    ([32, 4, 4, 8], [1, 1, 1, 2], 16, 0, True, "8"),     # x3 split over two ranks: + and - neighbour are the same peer
+    ([64, 8, 8, 6], [2, 1, 1, 1], 16, 0, False, "32"),   # x0 split, blocking exchange, bundle sweep with ghost halos
+    ([32, 16, 8, 6], [1, 2, 2, 1], 16, 0, True, "32"),   # 4 ranks: two split directions, interior + boundary launches
+    ([64, 16, 8, 6], [2, 2, 1, 1], 16, 3, False, "32"),  # the headline's mode: capacity ring, x3 undivided, windowed exchanges
+    ([8, 4, 4, 4], [2, 1, 1, 2], 32, 0, True, "8"),      # m = 32, general stencil
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,ring,overlap,blocks", NATIVE_CASES,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_native_transport_multi_rank(dims, grid, m, ring, overlap, blocks):
+    """The NATIVE bcg_comm implementation (comm_rccl.cpp: one ncclGroup of sends/receives per exchange, posting-order
+    matching of two messages to one peer, begin/end on a second stream with events, all-reduce of the Gram buffer) run by
+    2 and 4 processes sharing the GPU, with RCCL's seven calls replaced by a host-staged stand-in that keeps their matching
+    rules.  Every rank checks operator, Gram matrix and solve of its sub-lattice against the whole-lattice oracle."""
+    _run_ranks(dims, grid, m, False, ring, blocks=blocks, patch="16,2,2", overlap=overlap, native=True)
