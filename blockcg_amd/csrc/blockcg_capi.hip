@@ -358,11 +358,11 @@ int boundary_tile_list(bcg_context* c, int spb, const int** list, int* n) {
 
 // Profiling only: count the launches of each form of the stencil kernel ("stencil_form_k_hop4c" ...), so that tests
 // and tuning runs can tell which one a lattice shape gets.
-void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win) {
+void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win, bool plain = false) {
   if (!c->profiling) return;
   static const char* names[] = {"stencil_form_general", "stencil_form_k_hop4", "stencil_form_k_hop4c", "stencil_form_k_hop4b"};
   int form = bcg::hop_kernel_form(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win);
-  if (form == 2 && bcg::hop_uses_bundle(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win)) form = 3;
+  if (form == 2 && bcg::hop_uses_bundle(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win, plain)) form = 3;
   if (form >= 0 && form <= 3) c->prof[names[form]].count += 1;
 }
 
@@ -417,7 +417,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   }
   BCG_TRY(halo_field(c, in));
   if (fast) {
-    note_stencil_form(c, m, 0, bcg::HopWindow());
+    note_stencil_form(c, m, 0, bcg::HopWindow(), mode == bcg::HOP_PLAIN);
     ProfScope ps(c, name);
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                         p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune, 0);
@@ -544,7 +544,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   }
   BCG_TRY(halo_field(c, P));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
-    note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R});
+    note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
     ProfScope ps(c, "hop_ring");
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
                                         0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});

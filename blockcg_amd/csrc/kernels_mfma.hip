@@ -1447,7 +1447,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e1 = wave & 1, e2 = wave >> 1;
   dv2* const Cbase = reinterpret_cast<dv2*>(smem);                       // [2 slots][4 waves][CS]
-  dv2* const Lw = Cbase + 2 * NW * CS + wave * 2 * LSTAGE;               // this wave's two link images
+  // this wave's link image: ONE copy suffices -- the next step's links wait in registers and are parked at the end of the
+  // step, behind the wave's last read of the image (LDS operations of a wave are in order)
+  dv2* const Lw = Cbase + 2 * NW * CS + wave * LSTAGE;
   const int sw = lane / M, j = lane % M;
   const unsigned voff = static_cast<unsigned>((sw * 3 * M + j) * 16);   // byte offset of (site sw, colour 0, rhs j) in a row
   const int co = (sw + 1) * 3 * M + j;                                   // the same element in a row slot (colour c: + c*M)
@@ -1485,7 +1487,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     bo_f[k] = static_cast<unsigned>((e / 9) * 36 + e % 9) * 16;
     bo_g[k] = static_cast<unsigned>(e) * 16;
   }
-  int lstage = 0;
   bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
   const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
   unsigned seen1 = 0, seen2 = 0;
@@ -1558,8 +1559,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           rb3[k] = ld_link(reinterpret_cast<const dv2*>(q3 + (k_b3 ? bo_g[k] : bo_f[k])));
         }
     };
-    auto park_links = [&](int st) __attribute__((always_inline)) {
-      dv2* const Lf = Lw + st * LSTAGE;
+    auto park_links = [&]() __attribute__((always_inline)) {
+      dv2* const Lf = Lw;
 #pragma unroll
       for (int k = 0; k < RFW; ++k)
         if (lane + 64 * k < SPW * 36) Lf[36 + lane + 64 * k] = rf[k];
@@ -1627,7 +1628,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
       for (int c = 0; c < 3; ++c) Cm[co + c * M] = *reinterpret_cast<const dv2*>(own + voff + c * M * 16);
       fetch_links(lo);
-      park_links(lstage);
+      park_links();
     }
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
       const int step_n = vs0 + x3;
@@ -1648,9 +1649,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       }
       __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
       if (x3 + 1 < x3_end) fetch_links(x3 + 1);  // parked at the end of this step
-      const dv2* const Lf = Lw + lstage * LSTAGE;
+      const dv2* const Lf = Lw;
       const dv2* const Lb = Lf + NFW;
-      lstage ^= 1;
       const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;       // centre rows of the four waves (this slice)
       dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;  // this wave's slot for slice x3 + 1; holds slice x3 - 1
       double2 f[4][3], bk[4][3];
@@ -1752,7 +1752,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       // the LDS writes: the compiler cannot count across the step's branches) drains nothing.  The output stores and the
       // pacing atomics are issued behind it and are never waited for inside the step: k_hop4c parks at the top of the
       // next tile and drains them there, 13 % of its time.
-      if (x3 + 1 < x3_end) park_links(lstage);
+      if (x3 + 1 < x3_end) park_links();
       // park the +x3 row (own sites and halo) as the next step's centre row
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -2034,9 +2034,10 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
 }
 
 // k_hop4b (2 x 2 column bundles) serves whole launches of the column form whose patches are made of whole bundle tiles
-static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const HopPlan& pl, int cls) {
+// (at m = 8 the plain form only unless bundle_walk = 2: measured at 32^4, 0.36 vs 0.41 ms plain, 0.50 vs 0.44 ms with the Gram product)
+static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const HopPlan& pl, int cls, bool plain) {
   const int spw = 64 / m;
-  return pl.valid && pl.column && tune.sync.bundle_walk && cls == 0 && (m != 8 || tune.sync.bundle_walk > 1) &&
+  return pl.valid && pl.column && tune.sync.bundle_walk && cls == 0 && (m != 8 || plain || tune.sync.bundle_walk > 1) &&
          lat.L[1] % 2 == 0 && lat.L[2] % 2 == 0 && pl.hw.p1 % 2 == 0 && pl.hw.p2 % 2 == 0 && pl.hw.p0 % spw == 0 &&
          (pl.hw.p0 / spw) * (pl.hw.p1 / 2) * (pl.hw.p2 / 2) == pl.grid / 8;
 }
@@ -2055,13 +2056,13 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   if (pl.list && grid == 0) return 0;  // no boundary tiles
   const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
   // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
-  if (bundle_ok(M, lat, tune, pl, cls)) {
+  if (bundle_ok(M, lat, tune, pl, cls, mode == HOP_PLAIN)) {
     HopWalk hwb = hw;  // pacing of the bundle sweep: its own window (default none)
     if (tune.sync.bundle_window > 0 && hw.sync) hwb.sync_window = tune.sync.bundle_window;
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
     constexpr int SPW = 64 / M;
-    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPW + 2) * 3 * M) + 4 * 2 * ((SPW + 1) * 36 + 3 * SPW * 9));
+    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPW + 2) * 3 * M) + 4 * ((SPW + 1) * 36 + 3 * SPW * 9));
     const size_t lds = lds_u > lds_g ? lds_u : lds_g;
 #define BCG_LAUNCH4B(MM, MD, GR, RG)                                                                                \
   do {                                                                                                             \
@@ -2147,10 +2148,11 @@ int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTunin
   return !pl.valid ? -1 : (pl.column ? 2 : 1);
 }
 
-bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win) {
+bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
+                     bool plain) {
   if (!hop_can_split_tiles(m, lat)) return false;
   const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
-  return bundle_ok(m, lat, tune, plan_hop4(m, lat, mb, tune, tile_class, win), tile_class);
+  return bundle_ok(m, lat, tune, plan_hop4(m, lat, mb, tune, tile_class, win), tile_class, plain);
 }
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,

@@ -31,7 +31,7 @@ struct HopSync {
   int limit_ticks = 5000;        // 100 MHz ticks (50 us) a block waits before it gives up pacing
   bool column_walk = true;       // use k_hop4c (scalar row pointers, column sweep) where the walk allows it
   int bundle_walk = 1;           // k_hop4b (2 x 2 column bundles sharing rows through LDS) for whole launches: 0 off, 1 at
-                                 // m = 16 and 32, 2 also at m = 8 (one block per CU there: LDS)
+                                 // m = 16 and 32 and for the plain hop at m = 8, 2 for every launch at m = 8 too
   int bundle_window = 0;         // pacing window of k_hop4b (0 = unpaced, the measured optimum: its blocks re-use rows
                                  // through LDS, and waiting for the slowest block costs more than the L2 misses it saves)
 };
@@ -69,6 +69,7 @@ bool hop_can_split_tiles(int m, const LatticeDev& lat);
 // Which kernel launch_hop_fast will use: 0 general (k_hop_fast), 1 k_hop4 (tile counter), 2 k_hop4c (column sweep), -1 rejected
 int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win);
 // true when form 2 is served by k_hop4b (2 x 2 column bundles) rather than k_hop4c
-bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win);
+bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
+                     bool plain = false);
 
 }  // namespace bcg

@@ -516,10 +516,11 @@ def test_capacity_mode_arguments(bc):
 @pytest.mark.parametrize("m,dims,patch,blocks", [(16, [32, 8, 8, 6], "16,2,2", "32"), (16, [64, 4, 8, 4], "32,2,2", "64"),
                                                  (8, [64, 8, 8, 4], "32,2,2", "32"), (32, [16, 8, 8, 4], "8,2,2", "32")])
 @pytest.mark.parametrize("sync", ["0", "1", "4"])
-@pytest.mark.parametrize("bundle", ["0", "2"])
+@pytest.mark.parametrize("bundle", ["0", "1", "2"])
 def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, bundle, monkeypatch):
     """The column sweep in both forms: k_hop4c (one block per row of a patch slice, scalar row pointers; bundle = 0) and
-    k_hop4b (one block per 2 x 2 bundle of columns, rows shared through LDS; bundle = 2 enables it at m = 8 too), the
+    k_hop4b (one block per 2 x 2 bundle of columns, rows shared through LDS; bundle = 1, the default, uses it at m = 8 for
+    the plain hop only, bundle = 2 for every launch), the
     blocks of an XCD class paced by device counters (window 1 forces waits, 0 switches pacing off).  Operator, fused Gram
     product, a fixed number of iterations and capacity mode against the oracle; the profile shows which form ran."""
     monkeypatch.setenv("BCG_HOP_PATCH", patch)
@@ -551,8 +552,14 @@ def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, bundle, mon
         for s in range(len(shifts)):
             assert rel_err(X[s].download(), o["X"][s]) < 1e-10
         prof = ctx.profile()
-        want, other = ("stencil_form_k_hop4b", "stencil_form_k_hop4c") if bundle != "0" else ("stencil_form_k_hop4c", "stencil_form_k_hop4b")
-        assert prof.get(want, {}).get("count", 0) > 0 and other not in prof, prof.keys()
+        nb, nc = (prof.get(k, {}).get("count", 0) for k in ("stencil_form_k_hop4b", "stencil_form_k_hop4c"))
+        if bundle == "0":
+            assert nc > 0 and nb == 0, prof.keys()
+        elif bundle == "1" and m == 8:
+            # plain hop on bundles, the hop with the Gram product on rows (the ring's second stencil is not recorded)
+            assert nb > 0 and (nc > 0 or ring), prof.keys()
+        else:
+            assert nb > 0 and nc == 0, prof.keys()
         assert "stencil_form_k_hop4" not in prof and "stencil_form_general" not in prof
 
 
