@@ -7,7 +7,7 @@ Workload at N = 1: BASELINE.json configs[2], V = 64^4, m = 16 right-hand sides, 
 the largest configuration that fits one GPU (128^4 needs 2.4 TB).
 
 N > 1 is the ladder that ends at the BASELINE headline, configs[3] (V = 128^4, m = 16, 4 shifts on 8 GPUs): every
-GPU holds 64 x 64 x 64 x 128 sites (279.5 GB of the 288 GB, capacity mode with a ring of 8 x3-slices) and the process
+GPU holds 64 x 64 x 64 x 128 sites (281 GB of the 288 GiB, capacity mode with a ring of 16 x3-slices) and the process
 grid grows over x2, x1, x0 with x3 undivided:
     N = 2: 64 x 64 x 128 x 128 (grid 1,1,2,1)   N = 4: 64 x 128 x 128 x 128 (1,2,2,1)   N = 8: 128^4 (2,2,2,1)
 One process per GPU; halo faces (grouped ncclSend/ncclRecv) and the m x m all-reduce go over RCCL/xGMI through
@@ -103,7 +103,7 @@ def resolve_shape(world, local_dims, capacity):
     if local_dims is None:
         local_dims = [64, 64, 64, 128] if world > 1 else [64, 64, 64, 64]
     if capacity is None:
-        capacity = 8 if ladder else 0
+        capacity = 16 if ladder else 0  # measured on one GPU at this share: ring 16 140.4 ms, ring 8 142.6-144.6 ms per iteration
     return list(local_dims), capacity, ladder
 
 
@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=None, metavar="R",
                     help="capacity mode: keep the operator's intermediate field as a ring of R x3 slices "
                          "(bcg_capacity_mode); the process grid then leaves x3 undivided "
-                         "(default: 0 on one GPU, 8 on several with the default shape)")
+                         "(default: 0 on one GPU, 16 on several with the default shape)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     default_shape = args.local_dims is None and args.capacity is None
@@ -254,7 +254,7 @@ def main():
             "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
                                    f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)"
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
-                                      "(64^3x128 per GPU, capacity ring 8)" if default_shape else ""),
+                                      "(64^3x128 per GPU, capacity ring 16)" if default_shape else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
             "iterations_per_sec": its,
             "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,

@@ -2037,6 +2037,9 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
 // (at m = 8 the plain form only unless bundle_walk = 2: measured at 32^4, 0.36 vs 0.41 ms plain, 0.50 vs 0.44 ms with the Gram product)
 static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const HopPlan& pl, int cls, bool plain) {
   const int spw = 64 / m;
+  // short x3 windows (capacity ring 8: 6 slices) do not repay the bundle's column prologue -- two row loads before the
+  // first step -- (measured at 64^3 x 128: ring 8 144.6 vs 142.6 ms per iteration, ring 16 140.4 vs 141.1 ms)
+  if (pl.win.ring > 0 && pl.win.x3_n < 10 && tune.sync.bundle_walk < 2) return false;
   return pl.valid && pl.column && tune.sync.bundle_walk && cls == 0 && (m != 8 || plain || tune.sync.bundle_walk > 1) &&
          lat.L[1] % 2 == 0 && lat.L[2] % 2 == 0 && pl.hw.p1 % 2 == 0 && pl.hw.p2 % 2 == 0 && pl.hw.p0 % spw == 0 &&
          (pl.hw.p0 / spw) * (pl.hw.p1 / 2) * (pl.hw.p2 / 2) == pl.grid / 8;

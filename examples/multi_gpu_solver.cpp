@@ -8,7 +8,7 @@
 //     come from RANK / WORLD_SIZE / LOCAL_RANK (set by tools/launch_ranks.sh, mpirun, srun or torch.distributed.run);
 //     <idfile> is a path all ranks can see, used once to hand RCCL's 128-byte unique id from rank 0 to the others.
 //   e.g. 8 GPUs, the BASELINE headline shape:
-//     tools/launch_ranks.sh 8 examples/_build/multi_gpu_solver /tmp/bcg.id 128 128 128 128 2 2 2 1 0.1 1e-10 8
+//     tools/launch_ranks.sh 8 examples/_build/multi_gpu_solver /tmp/bcg.id 128 128 128 128 2 2 2 1 0.1 1e-10 16
 //
 // Build: see tests/test_cpp_dropin.py::test_multi_gpu_driver_builds (g++, -lblockcg_rccl -lblockcg_hip).
 #include <chrono>

@@ -65,6 +65,7 @@ OPERATOR_CASES = [
     ("32c4_m8_default", [32, 32, 32, 32], 8, "default"),
     ("64c3x32_m32_default", [64, 64, 64, 32], 32, "default"),
     ("64c3x128_m16_capacity8", [64, 64, 64, 128], 16, "capacity"),  # the per-GPU share of 128^4 on a (2,2,2,1) grid
+    ("64c3x128_m16_capacity16", [64, 64, 64, 128], 16, "capacity16"),  # ... with the ring bench.py --gpus 8 selects
 ]
 
 
@@ -78,8 +79,8 @@ def test_operator_production_geometry_vs_sampled_oracle(bc, orc, case, monkeypat
     monkeypatch.setenv("BCG_FORCE_TILE_CLASSES", "1" if mode == "classes" else "0")
     mass = 0.37
     ctx = bc.Context(dims)
-    if mode == "capacity":
-        ctx.capacity_mode(8)
+    if mode.startswith("capacity"):
+        ctx.capacity_mode(16 if mode == "capacity16" else 8)
     D = bc.dirac_op(ctx, mass, seed=SEED_U)
     psi = bc.block_fermion_field(ctx, m).setRandom(seed=SEED_PSI)
     out = bc.block_fermion_field(ctx, m)
@@ -119,6 +120,7 @@ REPLICA_CASES = [
     ("32c4_m8_S1", [16, 8, 8, 8], [2, 4, 4, 4], 8, [0.0], "default"),
     ("64c3x32_m32_S8", [16, 8, 8, 8], [4, 8, 8, 4], 32, [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0], "default"),
     ("64c3x128_m16_S4_capacity8", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity"),
+    ("64c3x128_m16_S4_capacity16", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity16"),  # bench.py --gpus 8
 ]
 
 
@@ -144,13 +146,13 @@ def test_replicated_solve_matches_oracle_on_base_lattice(bc, orc, case, monkeypa
     assert 3 < o["iterations"] < 2000
 
     ctx = bc.Context(dims)
-    if mode == "capacity":
-        ctx.capacity_mode(8)
+    if mode.startswith("capacity"):
+        ctx.capacity_mode(16 if mode == "capacity16" else 8)
     D = bc.dirac_op(ctx, mass, U=tile_sites(Ub, base, reps))
     B = bc.block_fermion_field(ctx, m, tile_sites(Bb, base, reps))
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
     info = bc.SBCGrQ(X, B, D, shifts, eps, eps, max_iterations=o["iterations"] + 50, trace_limit=ntrace,
-                     consume_B=(mode == "capacity"), return_info=True)
+                     consume_B=mode.startswith("capacity"), return_info=True)
     assert abs(info["iterations"] - o["iterations"]) <= 1, (info["iterations"], o["iterations"])
     tr, otr = info["trace"], o["trace"]
     for key in ("alpha", "rho", "beta_s"):
