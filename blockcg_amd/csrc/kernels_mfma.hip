@@ -318,12 +318,30 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
   GramAcc<M> G;
   gram_zero(G);
   const int64_t ntiles = (rows + 15) / 16;
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  constexpr bool AHEAD = M <= 16;
+  Tile<M> t, q;
+  if (AHEAD && tile < ntiles) {
+    tile_load<M>(t, T, tile * 16 + r, kq, tile * 16 + r < rows);
+    tile_load<M>(q, Q, tile * 16 + r, kq, tile * 16 + r < rows);
+  }
+  for (; tile < ntiles; tile += stride) {
     const int64_t row = tile * 16 + r;
     const bool ok = row < rows;
-    Tile<M> t, q;
-    tile_load<M>(t, T, row, kq, ok);
-    tile_load<M>(q, Q, row, kq, ok);
+    if (!AHEAD) {
+      tile_load<M>(t, T, row, kq, ok);
+      tile_load<M>(q, Q, row, kq, ok);
+    }
+    // the next tile's loads are in flight while this one is multiplied, transposed and accumulated (m <= 16: the
+    // registers allow it; at m = 32 the two extra tiles would cost the third block per CU)
+    Tile<M> tn, qn;
+    const int64_t nrow = (tile + stride) * 16 + r;
+    const bool nok = tile + stride < ntiles && nrow < rows;
+    if (AHEAD && tile + stride < ntiles) {
+      tile_load<M>(tn, T, nrow, kq, nok);
+      tile_load<M>(qn, Q, nrow, kq, nok);
+    }
     Acc<M> A;
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
@@ -340,6 +358,10 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
       for (int jb = 0; jb < JB; ++jb)
         a[jb] = *reinterpret_cast<const double2*>(tw + (4 * g + (lane >> 4)) * TLD + 2 * (16 * jb + (lane & 15)));
       gram_step<M>(G, a, a);
+    }
+    if (AHEAD && tile + stride < ntiles) {
+      t = tn;
+      q = qn;
     }
   }
   gram_block_store<M, NW>(G, scratch, partials, tid);
