@@ -179,3 +179,12 @@ def test_multi_gpu_driver_world_of_one(tmp_path):
         assert "SBCGrQ_iterations" in r.stdout
         res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
         assert len(res) == 4 and max(res) < 2e-9
+
+
+@pytest.mark.gpu
+def test_field_multiplier_overloads_on_the_gpu():
+    """Every (double | N x N) multiplier combination of add / rescale_add (inc/fields.hpp:69-90) and a write through
+    operator[] (:37) on the drop-in field type, against the same expressions evaluated on the host site by site."""
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "overload_probe.cpp"), "overload_probe")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OVERLOADS_OK" in r.stdout, r.stdout + r.stderr
