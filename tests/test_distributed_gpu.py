@@ -70,7 +70,8 @@ COLUMN_CASES = [
     ([64, 8, 8, 6], [2, 1, 1, 1], 16, 0),     # x0 divided: edge lanes patched from the ghost face, U_0 ghost
     ([32, 16, 8, 6], [1, 2, 1, 1], 16, 0),    # x1
     ([32, 8, 16, 12], [1, 1, 2, 2], 16, 0),   # x2 and x3, 4 ranks
-    ([64, 16, 8, 6], [2, 2, 1, 1], 16, 3),    # x0, x1 and capacity mode
+    ([64, 16, 8, 6], [2, 2, 1, 1], 16, 3),    # x0, x1 and capacity mode (one-slice windows: row form)
+    ([64, 8, 8, 24], [2, 1, 1, 1], 16, 12),   # capacity ring 12: ten-slice windows, the bundle sweep with ring addressing and ghosts
 ]
 
 
@@ -169,6 +170,7 @@ NATIVE_CASES = [
     ([32, 16, 8, 6], [1, 2, 2, 1], 16, 0, True, "32"),   # 4 ranks: two split directions, interior + boundary launches
     ([64, 16, 8, 6], [2, 2, 1, 1], 16, 3, False, "32"),  # the headline's mode: capacity ring, x3 undivided, windowed exchanges
     ([8, 4, 4, 4], [2, 1, 1, 2], 32, 0, True, "8"),      # m = 32, general stencil
+    ([32, 16, 8, 24], [1, 2, 1, 1], 16, 12, False, "32"),  # ring 12 (ten-slice windows): bundle sweep, ring addressing, x1 ghosts
 ]
 
 
