@@ -33,6 +33,15 @@ def _mock_transport():
     return lib
 
 
+def _sweep_mock_files():
+    """The stand-in transport leaves the last collectives' files of a run in /dev/shm (a rank cannot know when the others
+    have read them); every rank has exited by now."""
+    import glob
+    import shutil
+    for d in glob.glob("/dev/shm/bcg_mock_*"):
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False):
     world = 1
     for g in grid:
@@ -46,6 +55,8 @@ def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overl
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if native:
+        _sweep_mock_files()
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU_OK" in out.stdout
 
@@ -156,6 +167,7 @@ def test_bench_ranks_on_one_gpu_native_transport():
            "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
            "--local-dims", "32", "8", "8", "8", "--capacity", "4"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    _sweep_mock_files()
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     import json
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
