@@ -134,6 +134,13 @@ class Oracle:
                                              sites.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(out)))
         return out
 
+    def gram_generated(self, m, nsites, seed_a, seed_b):
+        """a^dagger b of two generated fields, chunked sums (no lattice-sized array); mirrored like hermitian_dot."""
+        out = np.empty((m, m), dtype=np.complex128)
+        self.lib.orc_gram_generated.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, _c_dbl_p]
+        self._chk(self.lib.orc_gram_generated(m, nsites, seed_a, seed_b, _dp(out)))
+        return _mat_out(out)
+
     def sbcgrq_generated(self, m, dims, seed_U, seed_B, mass, sigma, iterations):
         """SBCGrQ trace of the first `iterations` iterations on generated inputs (no lattice-sized numpy arrays)."""
         S = len(sigma)

@@ -107,6 +107,35 @@ int orc_apply_sampled(int m, int ndim, const int* dims, uint64_t seed_U, uint64_
   return 0;
 }
 
+// a^dagger b (m x m, column-major) of two GENERATED fields of `nsites` sites, accumulated in chunks of 4096 sites whose sums
+// are added in chunk order: the block inner product at sizes too large to hold (64^4 and up), inc/fields.hpp:103-122.
+int orc_gram_generated(int m, int64_t nsites, uint64_t seed_a, uint64_t seed_b, double* out) {
+  ORC_DISPATCH(m, {
+    constexpr int64_t kChunk = 4096;
+    const int64_t nchunk = (nsites + kChunk - 1) / kChunk;
+    std::vector<Mat> part(static_cast<size_t>(nchunk), Mat(M));
+    BLOCKCG_ORACLE_PARALLEL_FOR
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+      const int64_t x0 = ch * kChunk;
+      const int64_t n = std::min<int64_t>(kChunk, nsites - x0);
+      Field<M> fa(n);
+      Field<M> fb(n);
+      for (int64_t s = 0; s < n; ++s) {
+        generated_tile<M>(fa.site(s), seed_a, x0 + s);
+        generated_tile<M>(fb.site(s), seed_b, x0 + s);
+      }
+      hermitian_dot_lower_range(part[ch], fa, fb, 0, n);
+    }
+    Mat R(M);
+    for (int64_t ch = 0; ch < nchunk; ++ch)
+      for (size_t e = 0; e < R.a.size(); ++e) R.a[e] += part[ch].a[e];
+    for (int i = 1; i < M; ++i)
+      for (int j = 0; j < i; ++j) R(j, i) = std::conj(R(i, j));
+    store_mat(R, out);
+  });
+  return 0;
+}
+
 // SBCGrQ on generated inputs (gauge seed_U, source seed_B) without passing lattice-sized arrays through the caller: the
 // m x m coefficients of the first `max_iterations` iterations at sizes such as 64^4 (with orc_set_threads > 1).
 // Trace layout as orc_sbcgrq.  X is not returned.

@@ -166,3 +166,29 @@ def test_replicated_solve_matches_oracle_on_base_lattice(bc, orc, case, monkeypa
     bsite = (((x[3] % base[3]) * base[2] + x[2] % base[2]) * base[1] + x[1] % base[1]) * base[0] + x[0] % base[0]
     for s in range(len(shifts)):
         assert rel_err(X[s].download_sites(sites), o["X"][s][bsite]) < 1e-7, s
+
+
+GRAM_CASES = [("64c4_m16", [64, 64, 64, 64], 16), ("32c4_m8", [32, 32, 32, 32], 8), ("64c3x32_m32", [64, 64, 64, 32], 32)]
+
+
+@pytest.mark.parametrize("case", GRAM_CASES, ids=[c[0] for c in GRAM_CASES])
+def test_block_inner_products_at_full_size_vs_chunked_oracle(bc, orc, case):
+    """hermitian_dot (inc/fields.hpp:103-122) and thinQR's factor (:140-146) on generated, non-periodic fields of the full
+    per-GPU sizes, against Gram sums the oracle accumulates in chunks of 4096 sites from the generator (nothing of size V on
+    the host): the production grids of the MFMA Gram kernels and their fixed-order reductions."""
+    _, dims, m = case
+    ctx = bc.Context(dims)
+    A = bc.block_fermion_field(ctx, m).setRandom(seed=5)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=6)
+    orc.set_threads(16)
+    try:
+        want_ab = orc.gram_generated(m, ctx.V, 5, 6)
+        want_bb = orc.gram_generated(m, ctx.V, 6, 6)
+    finally:
+        orc.set_threads(1)
+    assert rel_err(A.hermitian_dot(B), want_ab) < 1e-12
+    G = B.hermitian_dot(B)
+    assert rel_err(G, want_bb) < 1e-12
+    R = B.thinQR()   # in place: B becomes Q
+    assert rel_err(R, orc.cholesky_upper(want_bb)) < 1e-11
+    assert rel_err(B.hermitian_dot(B), np.eye(m)) < 1e-11

@@ -56,3 +56,17 @@ def test_replicated_lattice_property(orc):
         assert rel_err(f["trace"][k], sc * o["trace"][k]) < 1e-11, k
     for s in range(len(shifts)):
         assert rel_err(f["X"][s], tile_sites(o["X"][s], base, reps)) < 1e-7
+
+
+def test_chunked_generated_gram_equals_whole_field_oracle(orc):
+    for m, V in ((16, 3 * 4096 + 17), (8, 100), (32, 5000), (3, 4096)):
+        a = orc.fill_field(m, V, 5)
+        b = orc.fill_field(m, V, 6)
+        want = orc.hermitian_dot(a, b)
+        for thr in (1, 4):
+            orc.set_threads(thr)
+            try:
+                got = orc.gram_generated(m, V, 5, 6)
+            finally:
+                orc.set_threads(1)
+            assert rel_err(got, want) < 1e-13
