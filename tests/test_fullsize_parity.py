@@ -192,3 +192,25 @@ def test_block_inner_products_at_full_size_vs_chunked_oracle(bc, orc, case):
     R = B.thinQR()   # in place: B becomes Q
     assert rel_err(R, orc.cholesky_upper(want_bb)) < 1e-11
     assert rel_err(B.hermitian_dot(B), np.eye(m)) < 1e-11
+
+
+@pytest.mark.parametrize("case", GRAM_CASES, ids=[c[0] for c in GRAM_CASES])
+def test_row_kernels_at_full_size_vs_sampled_oracle(bc, orc, case):
+    """add(rhs, m x m) (K5), rescale_add(m x m, rhs, b) (K6), add(rhs, double) (K3) and
+    multiply_upper_triangular_inverse_RHS (K7) -- inc/fields.hpp:70-90,125-136 -- are site-local, so the oracle evaluates
+    them on the generated tiles of the chosen sites only; the device runs its persistent full-size grids."""
+    _, dims, m = case
+    ctx = bc.Context(dims)
+    sites = chosen_sites(dims, n_special=200, n_random=300)
+    y0 = np.stack([orc.fill_field(m, 1, 7, first_global_site=int(s))[0] for s in sites])
+    b0 = np.stack([orc.fill_field(m, 1, 8, first_global_site=int(s))[0] for s in sites])
+    rng = np.random.default_rng(m)
+    M = rng.uniform(-1, 1, (m, m)) + 1j * rng.uniform(-1, 1, (m, m))
+    R = np.triu(rng.uniform(-1, 1, (m, m)) + 1j * rng.uniform(-1, 1, (m, m))) + 3.0 * np.eye(m)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=8)
+    new_y = lambda: bc.block_fermion_field(ctx, m).setRandom(seed=7)  # noqa: E731
+    assert np.array_equal(new_y().download_sites(sites), y0)
+    assert rel_err(new_y().add(B, M).download_sites(sites), orc.add_matrix(y0, b0, M)) < TOL_KERNEL
+    assert rel_err(new_y().rescale_add(M, B, 0.7).download_sites(sites), orc.rescale_add_matrix(y0, M, b0, 0.7)) < TOL_KERNEL
+    assert rel_err(new_y().add(B, -0.3).download_sites(sites), orc.add_scalar(y0, b0, -0.3)) < TOL_KERNEL
+    assert rel_err(new_y().multiply_upper_triangular_inverse_RHS(R).download_sites(sites), orc.tri_solve_rhs(y0, R)) < 1e-12
