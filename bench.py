@@ -10,6 +10,8 @@ N > 1 is the ladder that ends at the BASELINE headline, configs[3] (V = 128^4, m
 GPU holds 64 x 64 x 64 x 128 sites (281 GB of the 288 GiB, capacity mode with a ring of 16 x3-slices) and the process
 grid grows over x2, x1, x0 with x3 undivided:
     N = 2: 64 x 64 x 128 x 128 (grid 1,1,2,1)   N = 4: 64 x 128 x 128 x 128 (1,2,2,1)   N = 8: 128^4 (2,2,2,1)
+`python bench.py --gpus N` starts its N ranks itself (fresh child processes under torch.distributed.run, before this
+process has imported torch or touched a GPU); under an existing launcher (WORLD_SIZE set) it is one of the ranks.
 One process per GPU; halo faces (grouped ncclSend/ncclRecv) and the m x m all-reduce go over RCCL/xGMI through
 libblockcg_rccl.so (native code, include/blockcg_rccl.h); torch.distributed (gloo) is only the launcher's control plane
 (rendezvous of RCCL's unique id, the barrier around the timed region and the max over ranks).
@@ -35,23 +37,27 @@ SHIFTS = [0.0, 1e-6, 1e-4, 1e-2, 1e-5, 1e-3, 1e-1, 1.0]  # SURVEY.md section 8d;
 MASS = 1e-3
 
 
-def kernel_bytes(name, V, m, S, ndim):
-    """Algorithmic HBM bytes of ONE launch of a kernel class ('Kernels'): s = 48 m bytes per
-    site of a field, g = 144 ndim bytes of links per site."""
-    s, g = 48.0 * m, 144.0 * ndim
-    table = {
-        "hop": 2 * s + g,            # read in, write out, read links
-        "hop_shifted": 3 * s + g,    # + read P0
-        "hop_shifted_gram": 3 * s + g,
-        "block_axpy": 3 * s,         # read x, read y, write y
-        "block_xpay": 3 * s,
-        "trisolve": 2 * s,
-        "gram_pair": 2 * s,
-        "gram_self": 1 * s,
-        "phaseB": 3 * s,             # Q -= T alpha (+ Gram of the new Q): read T, Q; write Q
-        "phaseC": (2 + 4 * S) * s,   # read Q, X_s, P_s; write Q, X_s, P_s
-    }
-    return V * table[name] if name in table else None
+def descendants(pid):
+    """PIDs of every live descendant of `pid` (from /proc), children before parents' siblings -- the exact processes this
+    script started, for the timeout path."""
+    kids = {}
+    for d in os.listdir("/proc"):
+        if not d.isdigit():
+            continue
+        try:
+            with open(f"/proc/{d}/stat") as f:
+                st = f.read()
+            ppid = int(st[st.rindex(")") + 2:].split()[1])
+        except (OSError, ValueError):
+            continue
+        kids.setdefault(ppid, []).append(int(d))
+    out, todo = [], [pid]
+    while todo:
+        p = todo.pop()
+        for k in kids.get(p, []):
+            out.append(k)
+            todo.append(k)
+    return out
 
 
 def cpu_baseline(m, S, shifts, mass, budget_iters=32):
@@ -97,6 +103,61 @@ def cpu_baseline(m, S, shifts, mass, budget_iters=32):
     return out
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks as fresh child processes
+    -- `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` -- relay rank 0's JSON line and the exit
+    code.  The parent never imports torch or blockcg_amd and makes no GPU call (a process that has initialised the GPU must
+    not be replaced, and N ranks must not race to build): it compiles the libraries once with make, picks a free port,
+    and kills the whole process group on a timeout (BCG_BENCH_TIMEOUT seconds, default 1500)."""
+    import signal
+    import socket
+    import subprocess
+    csrc = os.path.join(ROOT, "blockcg_amd", "csrc")
+    targets = [["-j4"]]  # libblockcg_hip.so + libblockcg_rccl.so
+    if os.path.basename(os.environ.get("BCG_RCCL_LIB", "")) == "libblockcg_rccl_mock.so":
+        targets.append(["mock"])  # rehearsal transport (several ranks on one GPU)
+    for t in targets:
+        r = subprocess.run(["make", "-C", csrc, "-s"] + t, stdout=sys.stderr)
+        if r.returncode != 0:
+            sys.exit(f"bench.py: building the libraries failed (make rc {r.returncode})")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    timeout = float(os.environ.get("BCG_BENCH_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        ranks = descendants(proc.pid)       # the launcher's workers (it starts each in a session of its own)
+        proc.send_signal(signal.SIGTERM)    # torch.distributed.run forwards it to its workers
+        try:
+            out, _ = proc.communicate(timeout=15)
+        except subprocess.TimeoutExpired:
+            out = None
+        for pid in ranks + [proc.pid]:      # whatever is left: exactly the processes started here
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        if out is None:
+            out, _ = proc.communicate()
+        sys.stdout.write(out or "")
+        sys.exit(f"bench.py: the {args.gpus} ranks did not finish within {timeout:.0f} s; launcher and ranks killed")
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    other = [ln for ln in (out or "").splitlines() if not ln.startswith("{")]
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
+    if proc.returncode != 0:
+        sys.exit(proc.returncode if proc.returncode > 0 else 1)
+    if not lines:
+        sys.exit("bench.py: the ranks exited cleanly but rank 0 printed no JSON line")
+    print(lines[-1], flush=True)
+
+
 def resolve_shape(world, local_dims, capacity):
     """(sites per GPU, capacity ring, on-the-headline-ladder?) for a world size: the defaults documented at the top."""
     ladder = world > 1 and local_dims is None
@@ -123,7 +184,11 @@ def main():
                          "(bcg_capacity_mode); the process grid then leaves x3 undivided "
                          "(default: 0 on one GPU, 16 on several with the default shape)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BCG_BENCH_TEST_HANG"):  # tests/test_bench_launcher.py: a rank that never finishes
+        time.sleep(3600)
     default_shape = args.local_dims is None and args.capacity is None
     args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity)
 
@@ -199,10 +264,11 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile()
     ctx.profiling(False)
+    bytes_in_use = mem_total - mem_free
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt, float(bytes_in_use)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, bytes_in_use = float(t[0].item()), int(t[1].item())
     residual = st.residual
     st.end()
     if comm is not None and comm.error is not None:
@@ -220,10 +286,15 @@ def main():
         hbm_gbps = bytes_iter_total * its / 1e9
         # dominant kernel of the timed region, from the HIP-event timings taken inside it
         roof = None
-        if prof:
-            name = max((k for k in prof if not k.startswith("stencil_form_")), key=lambda k: prof[k]["ms"])
-            avg_ms = prof[name]["ms"] / prof[name]["count"]
-            kb = kernel_bytes(name, ctx.V, m, S, ndim)
+        kernels = {k: v for k, v in prof.items() if not k.startswith("stencil_form_") and v.get("bytes", 0) > 0}
+        if kernels:
+            # `bytes` = the ALGORITHMIC bytes of the launches timed under that name (accumulated by the library per launch:
+            # per-site figure of DESIGN.md section 4 x the sites the launch processes), `ms` = HIP events on the context's
+            # stream around them: right for split launches (phase C in two launches, capacity-mode windows) as well
+            name = max(kernels, key=lambda k: kernels[k]["ms"])
+            e = kernels[name]
+            avg_ms = e["ms"] / e["count"]
+            kb = e["bytes"] / e["count"]
             # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes
             # (tools/profile_round.sh -> profiles/hbm_traffic.json); they are quoted only for the shape they were taken at
             traffic, traffic_source, stencil_ratio = None, None, None
@@ -237,15 +308,18 @@ def main():
                     traffic_source = f"profiles/hbm_traffic.json ({shape.get('measured', 'separate rocprofv3 --pmc passes')})"
                     sr = {}
                     for kn in ("hop", "hop_shifted_gram"):
-                        if kn in tj and kernel_bytes(kn, ctx.V, m, S, ndim):
-                            sr[kn] = tj[kn]["bytes_per_launch"] / kernel_bytes(kn, ctx.V, m, S, ndim)
+                        if kn in tj and kn in kernels:
+                            sr[kn] = tj[kn]["bytes_per_launch"] / (kernels[kn]["bytes"] / kernels[kn]["count"])
                     stencil_ratio = sr or None
-            if kb is not None:
-                ach = kb / (avg_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                        "avg_launch_ms": avg_ms, "launches": prof[name]["count"], "algorithmic_bytes_per_launch": kb,
-                        "stencil_traffic_ratio": stencil_ratio}
+            ach = kb / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                    "avg_launch_ms": avg_ms, "launches": e["count"], "algorithmic_bytes_per_launch": kb,
+                    "stencil_traffic_ratio": stencil_ratio,
+                    "per_kernel_frac": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                        for k, v in kernels.items() if v["ms"] > 0}}
+            # algorithmic bytes are a lower bound of the traffic: a fraction above 1 is an accounting error, not a result
+            assert all(f <= 1.0 for f in roof["per_kernel_frac"].values()) and roof["frac"] <= 1.0, roof
         out = {
             "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
             "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -264,7 +338,9 @@ def main():
             "stencil_kernel_launches": {k[len("stencil_form_"):]: v["count"] for k, v in prof.items() if k.startswith("stencil_form_")},
             "capacity_ring_slices": args.capacity,
             "device_bytes_planned": ctx.sbcgrq_device_bytes(m, S, consume_B=True),
-            "device_bytes_in_use": mem_total - mem_free, "device_bytes_total": mem_total,
+            "device_bytes_in_use": bytes_in_use, "device_bytes_total": mem_total,  # max over ranks
+            "comm_ms_per_iteration": {k: round(v["ms"] / K, 4) for k, v in prof.items()
+                                      if k.startswith("halo_exchange") or k in ("allreduce", "pack_faces")} if world > 1 else None,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -66,9 +66,13 @@ struct ProfScope {
   bcg_context* c;
   bcg::ProfEntry* e = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(bcg_context* ctx, const char* name) : c(ctx) {
+  // alg_bytes: the ALGORITHMIC HBM bytes of what is launched inside the scope (per-site figure x the
+  // sites this launch processes); summed per kernel class so that bench.py's roofline is right for split launches
+  // (phase C in two launches, capacity-mode windows) too.
+  ProfScope(bcg_context* ctx, const char* name, double alg_bytes = 0.0) : c(ctx) {
     if (!c->profiling) return;
     e = &c->prof[name];
+    e->bytes += alg_bytes;
     a = take();
     b = take();
     (void)hipEventRecord(a, c->stream);
@@ -200,6 +204,12 @@ int ensure_staging(bcg_context* c, size_t bytes) {
 }
 
 inline int64_t rows_of(const bcg_context* c) { return c->lat.V * 3; }
+// algorithmic bytes: `fields` passes over a width-m field (s = 48 m bytes per site) plus `links` passes over the gauge
+// links (g = 144 ndim bytes per site), over the fraction num/den of the local volume
+inline double alg_bytes(const bcg_context* c, int m, double fields, double links = 0.0, int64_t num = 1, int64_t den = 1) {
+  return static_cast<double>(c->lat.V) * (fields * 48.0 * m + links * 144.0 * c->ndim) * static_cast<double>(num) /
+         static_cast<double>(den);
+}
 inline size_t field_bytes(const bcg_context* c, int m) { return static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2); }
 
 // ---- halo exchange -----------------------------------------------------------------------------
@@ -392,7 +402,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     int nb1, nb2;
     note_stencil_form(c, m, 1, bcg::HopWindow());
     {
-      ProfScope ps(c, name);
+      ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));  // both tile classes: counted here
       nb1 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                  p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, /*interior*/ 1);
     }
@@ -418,12 +428,12 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   BCG_TRY(halo_field(c, in));
   if (fast) {
     note_stencil_form(c, m, 0, bcg::HopWindow(), mode == bcg::HOP_PLAIN);
-    ProfScope ps(c, name);
+    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                         p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune, 0);
     if (gram) *gram_blocks = nb;
   } else {
-    ProfScope ps(c, name);
+    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
     bcg::launch_hop_generic(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                             p ? p->d : nullptr, c0);
   }
@@ -460,7 +470,7 @@ int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool m
   const int m = a->m;
   int nblocks;
   {
-    ProfScope ps(c, a == b ? "gram_self" : "gram_pair");
+    ProfScope ps(c, a == b ? "gram_self" : "gram_pair", alg_bytes(c, m, a == b ? 1 : 2));
     if (fast_rows(c, m)) nblocks = bcg::launch_gram_mfma(c->stream, m, rows_of(c), a->d, b->d, c->partials, kFastBlocks);
     else nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(c), a->d, b->d, c->partials, kMaxGramBlocks);
   }
@@ -472,7 +482,7 @@ int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double
   const double2* Md;
   BCG_TRY(upload_mat(c, M, &Md));
   {
-    ProfScope ps(c, name);
+    ProfScope ps(c, name, alg_bytes(c, y->m, (x && x != y) ? 3 : 2));
     if (fast_rmul(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
     else bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
   }
@@ -483,7 +493,7 @@ int trisolve(bcg_context* c, bcg_field* y, const CMat& R) {
   const double2* Rd;
   BCG_TRY(upload_mat(c, R, &Rd));
   {
-    ProfScope ps(c, "trisolve");
+    ProfScope ps(c, "trisolve", alg_bytes(c, y->m, 2));
     bcg::launch_trisolve_generic(c->stream, y->m, rows_of(c), y->d, Rd);
   }
   return check_launch(c, "trisolve");
@@ -545,7 +555,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   BCG_TRY(halo_field(c, P));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
     note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
-    ProfScope ps(c, "hop_ring");
+    ProfScope ps(c, "hop_ring", alg_bytes(c, m, 2, 1, n, L3));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
                                         0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});
     if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
@@ -566,7 +576,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     next = hi + 1;
     BCG_TRY(halo_window(c, m, ring, lo, hi - lo, R));
     {
-      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring");
+      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring", alg_bytes(c, m, 3, 1, hi - lo, L3));
       const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                           c0, c->partials + static_cast<size_t>(total) * m * m, gram, kFastBlocks, tune, 0,
                                           bcg::HopWindow{lo, hi - lo, R});
@@ -610,7 +620,7 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
   BCG_TRY(upload_mat(c, na, &Md));
   int nb;
   {
-    ProfScope ps(c, "phaseB");
+    ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
     nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, c->row_blocks_B);
   }
   BCG_TRY(check_launch(c, "phaseB"));
@@ -648,7 +658,8 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     const double2* Md;
     BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
     {
-      ProfScope ps(c, "phaseC");
+      // the launch that applies rho^-1 reads and writes Q; a later launch of the same iteration (m = 32) re-reads it
+      ProfScope ps(c, "phaseC", alg_bytes(c, m, (first ? 2 : 1) + 4 * ns));
       bcg::launch_phaseC(c->stream, m, rows_of(c), Q->d, Xp, Pp, ns, Md, first, c->row_blocks_C);
     }
     BCG_TRY(check_launch(c, "phaseC"));
@@ -878,6 +889,7 @@ int bcg_profile_reset(bcg_context* c) {
   for (auto& kv : c->prof) {
     kv.second.ms = 0;
     kv.second.count = 0;
+    kv.second.bytes = 0;
   }
   return BCG_OK;
 }
@@ -893,7 +905,8 @@ const char* bcg_profile_json(bcg_context* c) {
     if (kv.second.count == 0) continue;
     if (!first) os << ", ";
     first = false;
-    os << "\"" << kv.first << "\": {\"ms\": " << kv.second.ms << ", \"count\": " << kv.second.count << "}";
+    os << "\"" << kv.first << "\": {\"ms\": " << kv.second.ms << ", \"count\": " << kv.second.count
+       << ", \"bytes\": " << kv.second.bytes << "}";
   }
   os << "}";
   c->prof_json = os.str();
@@ -1243,7 +1256,7 @@ int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_fiel
       BCG_TRY(ensure_scratch(c));
       int nb;
       {
-        ProfScope ps(c, "hop_residual");
+        ProfScope ps(c, "hop_residual", alg_bytes(c, m, 3, 1));  // reads tmp, X_s, B and the links; writes nothing
         nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, tmp->d, c->halo_recv, const_cast<double2*>(B->d),
                                   bcg::HOP_RESID, X[s]->d, mass * mass + sigma[s], c->partials, true, kFastBlocks, c->hop_tune, 0);
       }

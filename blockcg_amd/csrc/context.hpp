@@ -29,6 +29,7 @@ namespace bcg {
 struct ProfEntry {
   double ms = 0.0;
   long count = 0;
+  double bytes = 0.0;  // algorithmic HBM bytes of the launches timed under this name
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 

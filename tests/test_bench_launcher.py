@@ -1,0 +1,60 @@
+"""`python bench.py --gpus N` as the driver types it (no launcher around it, WORLD_SIZE unset): the parent must start the
+ranks as fresh children before it has imported torch or the library, relay the line, propagate failures and never leave
+ranks behind.  CPU-only here; the same bare command with real ranks on a GPU is tests/test_distributed_gpu.py."""
+import os
+import subprocess
+import sys
+import time
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", **extra)
+    return env
+
+
+def test_parent_imports_neither_torch_nor_the_library():
+    code = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "bad = [m for m in sys.modules if m == 'torch' or m.startswith('torch.') or m.startswith('blockcg_amd') or m == 'oracle']\n"
+        "assert not bad, bad\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "assert 'libamdhip64' not in maps and 'libblockcg' not in maps and 'libhsa-runtime' not in maps\n"
+        "assert bench.descendants(os.getpid()) == []\n"
+        "print('PARENT_CLEAN')\n")
+    out = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PARENT_CLEAN" in out.stdout, out.stdout + out.stderr
+
+
+def test_bare_multi_gpu_command_propagates_rank_failure():
+    """No GPU in this container: every rank fails at context creation (the product has no CPU fallback) and the bare
+    command must come back non-zero, promptly, with the reason on stderr -- not hang, not rc 0."""
+    t0 = time.time()
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--local-dims", "8", "4", "4", "4",
+                          "--no-cpu-baseline"], env=_clean_env(BCG_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "no usable HIP device" in out.stderr or "No HIP GPUs" in out.stderr or "BCG_ERR_NO_DEVICE" in out.stderr, out.stderr[-3000:]
+    assert time.time() - t0 < 300
+
+
+def test_bare_multi_gpu_command_kills_hung_ranks():
+    env = _clean_env(BCG_BENCH_TEST_HANG="1", BCG_BENCH_TIMEOUT="8")
+    proc = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--local-dims", "8", "4", "4", "4"],
+                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.path.insert(0, ROOT)
+    import bench
+    time.sleep(6)  # the ranks are up (and asleep) by now
+    started = bench.descendants(proc.pid)
+    assert len(started) >= 3, started  # the launcher and two ranks
+    out, err = proc.communicate(timeout=120)
+    assert proc.returncode != 0 and "did not finish" in err, err[-2000:]
+    time.sleep(0.5)
+    alive = [p for p in started if os.path.exists(f"/proc/{p}") and "Z" not in open(f"/proc/{p}/stat").read().split(")")[-1].split()[0]]
+    assert not alive, alive

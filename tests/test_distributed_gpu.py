@@ -175,6 +175,33 @@ def test_bench_ranks_on_one_gpu_native_transport():
     assert d["config"]["process_grid"] == [1, 2, 2, 1] and d["config"]["global_dims"] == [32, 16, 16, 8] and d["value"] > 0
 
 
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bare_bench_command_starts_its_own_ranks(gpus):
+    """The command line the round-end driver types -- `python bench.py --gpus N ...`, no launcher, WORLD_SIZE unset: the
+    parent starts the N ranks as fresh children before touching a GPU (tests/test_bench_launcher.py checks the parent on the
+    CPU) and relays rank 0's line.  Here with real ranks: native transport over the host-staged stand-in, all on GPU 0,
+    capacity ring (the headline's mode)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32",
+               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+           "--local-dims", "32", "8", "8", "8", "--capacity", "4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    _sweep_mock_files()
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    grid = {2: [1, 1, 2, 1], 4: [1, 2, 2, 1]}[gpus]
+    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert d["config"]["transport"] == "rccl" and d["capacity_ring_slices"] == 4 and d["config"]["process_grid"] == grid
+    assert d["config"]["global_dims"] == [32 * grid[0], 8 * grid[1], 8 * grid[2], 8]
+    comm = d["comm_ms_per_iteration"]
+    assert comm and comm["allreduce"] > 0 and comm["pack_faces"] > 0 and any(k.startswith("halo_exchange") for k in comm)
+    assert d["roofline"] and 0 < d["roofline"]["frac"] <= 1 and d["device_bytes_in_use"] > 0
+
+
 NATIVE_CASES = [
     # dims,             grid,          m,  ring, overlap (split exchange: second stream + events), blocks
     ([32, 4, 4, 8], [1, 1, 1, 2], 16, 0, True, "8"),     # x3 split over two ranks: + and - neighbour are the same peer
