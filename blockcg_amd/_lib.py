@@ -6,6 +6,7 @@ gfx950 device bcg_context_create returns BCG_ERR_NO_DEVICE (surfaced as BlockCGE
 import ctypes
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BCG_LIB") or os.path.join(_HERE, "_build", "libblockcg_hip.so")  # BCG_LIB: A/B builds
@@ -121,10 +122,63 @@ def build(verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+HIP_RUNTIME = None  # which HIP runtime this process ended up with: "torch" | "torch-bundle" | "system"
+
+
+def single_hip_runtime(extra=()):
+    """One ROCr per process.  This image's torch wheel bundles its own libamdhip64.so / libhsa-runtime64.so / librccl.so
+    (unversioned SONAMEs) beside the system ROCm this library links (libamdhip64.so.7); whichever of two ROCr instances
+    initialises second sees "No HIP GPUs are available".  torch loads its bundle RTLD_GLOBAL, so with torch imported FIRST
+    the library's HIP symbols bind to the bundle and there is one runtime.  A host that imports blockcg_amd first would arm
+    the trap for a later `import torch`; so, when torch is installed but not imported yet, its bundled runtime is mapped
+    here RTLD_GLOBAL (torch itself is NOT imported) and both end up on the same instance, in either import order.
+    BCG_HIP_RUNTIME=system opts out (a host that never imports torch and wants /opt/rocm's runtime).  If a system HIP
+    runtime is already mapped by something else, it is too late to unify: warn, naming the fix."""
+    global HIP_RUNTIME
+    import importlib.util
+    import warnings
+    if "torch" in sys.modules:
+        HIP_RUNTIME = "torch"
+        return HIP_RUNTIME
+    if HIP_RUNTIME == "system" and not extra:
+        return HIP_RUNTIME
+    if os.environ.get("BCG_HIP_RUNTIME", "") == "system":
+        HIP_RUNTIME = "system"
+        return HIP_RUNTIME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    tlib = os.path.join(os.path.dirname(spec.origin), "lib") if spec is not None and spec.origin else None
+    if tlib is None or not os.path.exists(os.path.join(tlib, "libamdhip64.so")):
+        HIP_RUNTIME = "system"
+        return HIP_RUNTIME
+    try:
+        with open("/proc/self/maps") as f:
+            mapped = {ln.split()[-1] for ln in f if "libamdhip64" in ln or "libhsa-runtime64" in ln}
+    except OSError:
+        mapped = set()
+    foreign = sorted(p for p in mapped if not p.startswith(tlib))
+    if foreign and HIP_RUNTIME != "torch-bundle":
+        warnings.warn(f"blockcg_amd: a HIP runtime is already mapped from {foreign[0]} and torch (with its own bundled ROCm "
+                      f"runtime in {tlib}) has not been imported: a later `import torch` in this process will see no GPU. "
+                      "Import torch before anything that loads libamdhip64, or set BCG_HIP_RUNTIME=system if torch is never "
+                      "used here.", RuntimeWarning, stacklevel=3)
+        HIP_RUNTIME = "system"
+        return HIP_RUNTIME
+    for name in ("libhsa-runtime64.so", "libamdhip64.so") + tuple(extra):
+        path = os.path.join(tlib, name)
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    HIP_RUNTIME = "torch-bundle"
+    return HIP_RUNTIME
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    single_hip_runtime()
     if not os.path.exists(LIB_PATH):
         # a fresh checkout: compile once with hipcc (it cross-compiles gfx950 without a GPU); there is no CPU fallback
         try:

@@ -1,14 +1,13 @@
 // libblockcg_rccl.so: bcg_comm on RCCL (include/blockcg_rccl.h).  Host code only; the transfers are RCCL's kernels.
 #include <hip/hip_runtime.h>
-#ifdef BCG_RCCL_MOCK  // tests only: several ranks on ONE GPU (tests/cpp/mock_rccl.hpp); never part of libblockcg_rccl.so
-#include "../../tests/cpp/mock_rccl.hpp"
-#else
+#ifndef BCG_RCCL_MOCK  // the test-only twin (make mock) force-includes a stand-in for these declarations instead
 #include <rccl/rccl.h>
 #endif
 #include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -66,11 +65,20 @@ int post_group(bcg_rccl_comm* c, hipStream_t stream, int n, const int* peer_send
     }
   }
   RCCL_OK(c, ncclGroupStart());
-  for (int k = 0; k < n; ++k) {
-    RCCL_OK(c, ncclSend(static_cast<const char*>(send) + off_s[k], nbytes[k], ncclChar, peer_send[k], c->comm, stream));
-    RCCL_OK(c, ncclRecv(static_cast<char*>(recv) + off_r[k], nbytes[k], ncclChar, peer_recv[k], c->comm, stream));
+  ncclResult_t bad = ncclSuccess;
+  const char* what = "";
+  for (int k = 0; k < n && bad == ncclSuccess; ++k) {
+    bad = ncclSend(static_cast<const char*>(send) + off_s[k], nbytes[k], ncclChar, peer_send[k], c->comm, stream);
+    what = "ncclSend";
+    if (bad != ncclSuccess) break;
+    bad = ncclRecv(static_cast<char*>(recv) + off_r[k], nbytes[k], ncclChar, peer_recv[k], c->comm, stream);
+    what = "ncclRecv";
   }
-  RCCL_OK(c, ncclGroupEnd());
+  // the group is closed on EVERY path: a group left open on this thread would swallow each later RCCL call (the
+  // all-reduce, the next exchange, the barrier) without launching it, and the peers would hang instead of seeing an error
+  const ncclResult_t end = ncclGroupEnd();
+  if (bad != ncclSuccess) { fail(c, std::string(what) + ": " + ncclGetErrorString(bad)); return 1; }
+  if (end != ncclSuccess) { fail(c, std::string("ncclGroupEnd: ") + ncclGetErrorString(end)); return 1; }
   return 0;
 }
 
@@ -97,6 +105,13 @@ int cb_allreduce(void* user, void* buf, size_t count) {
   return 0;
 }
 
+// The rendezvous file of THIS launch: `path`, or `path.<BCG_RUN_TOKEN>` when the launcher exports a per-launch token
+// (tools/launch_ranks.sh does), so that ranks of a new launch can never pick up the id a previous launch left behind.
+std::string id_file_of(const char* path) {
+  const char* tok = std::getenv("BCG_RUN_TOKEN");
+  return tok && *tok ? std::string(path) + "." + tok : std::string(path);
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,8 +127,10 @@ int bcg_rccl_get_unique_id(void* out) {
   return BCG_OK;
 }
 
-int bcg_rccl_unique_id_via_file(const char* path, int rank, double timeout_s, void* out) {
-  if (!path || !out) return BCG_ERR_INVALID;
+int bcg_rccl_unique_id_via_file(const char* path_arg, int rank, double timeout_s, void* out) {
+  if (!path_arg || !out) return BCG_ERR_INVALID;
+  const std::string path_s = id_file_of(path_arg);
+  const char* path = path_s.c_str();
   if (rank == 0) {
     if (bcg_rccl_get_unique_id(out) != BCG_OK) return BCG_ERR_COMM;
     const std::string tmp = std::string(path) + ".tmp." + std::to_string(static_cast<long>(getpid()));
@@ -142,11 +159,24 @@ int bcg_rccl_unique_id_via_file(const char* path, int rank, double timeout_s, vo
   }
 }
 
+int bcg_rccl_unique_id_file_done(const char* path, int rank, bcg_rccl_comm* comm) {
+  if (!path || !comm) return BCG_ERR_INVALID;
+  const int rc = bcg_rccl_barrier(comm);  // every rank holds the communicator, so every rank has read the file
+  if (rc != BCG_OK) return rc;
+  if (rank == 0) (void)std::remove(id_file_of(path).c_str());
+  return BCG_OK;
+}
+
 int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int world, bcg_rccl_comm** out) {
   if (!ctx || !id_bytes || !out || world < 1 || rank < 0 || rank >= world) {
     g_err = "bcg_comm_rccl_create: bad arguments";
     return BCG_ERR_INVALID;
   }
+  struct RestoreDevice {  // the caller's current device is its own business
+    int prev = -1;
+    RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } restore_device;
   bcg_rccl_comm* c = new bcg_rccl_comm();
   c->ctx = ctx;
   c->rank = rank;

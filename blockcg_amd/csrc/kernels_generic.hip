@@ -112,7 +112,9 @@ struct GDims {
 };
 
 // ---------------------------------------------------------------------------------------------
-__global__ void k_axpby(double2* __restrict__ y, double a, const double2* __restrict__ x, double b, int64_t n) {
+// y == x is allowed (add(rhs = *this, a), inc/fields.hpp:70-77 accepts it): each element is read before it is written and
+// no other thread touches it, so the pointers carry no __restrict__.
+__global__ void k_axpby(double2* y, double a, const double2* x, double b, int64_t n) {
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const double2 yv = y[i], xv = x[i];

@@ -159,6 +159,7 @@ class block_fermion_field {
     return *this;
   }
   block_fermion_field& add(const block_fermion_field& rhs, const block_matrix<N_rhs>& rhs_multiplier) {
+    if (&rhs == this) return add(block_fermion_field(rhs), rhs_multiplier);  // the reference accepts rhs == *this (:74)
     dev2(rhs);
     blockcg::check(bcg_field_add_matrix(f_, rhs.f_, reinterpret_cast<const double*>(rhs_multiplier.data())), lat_->ctx(), "add");
     return *this;
@@ -171,6 +172,7 @@ class block_fermion_field {
   }
   block_fermion_field& rescale_add(const block_matrix<N_rhs>& lhs_multiplier, const block_fermion_field& rhs,
                                    double rhs_multiplier) {
+    if (&rhs == this) return rescale_add(lhs_multiplier, block_fermion_field(rhs), rhs_multiplier);
     dev2(rhs);
     blockcg::check(bcg_field_rescale_add_matrix(f_, reinterpret_cast<const double*>(lhs_multiplier.data()), rhs.f_, rhs_multiplier),
                    lat_->ctx(), "rescale_add");
@@ -180,14 +182,16 @@ class block_fermion_field {
   // uses, are composed from the kernels above (two passes).
   block_fermion_field& rescale_add(double lhs_multiplier, const block_fermion_field& rhs,
                                    const block_matrix<N_rhs>& rhs_multiplier) {
+    if (&rhs == this) return rescale_add(lhs_multiplier, block_fermion_field(rhs), rhs_multiplier);
     dev2(rhs);
-    blockcg::check(bcg_field_rescale_add_scalar(f_, lhs_multiplier, f_, 0.0), lat_->ctx(), "rescale_add");
+    blockcg::check(bcg_field_rescale_add_scalar(f_, lhs_multiplier, rhs.f_, 0.0), lat_->ctx(), "rescale_add");  // scale only
     blockcg::check(bcg_field_add_matrix(f_, rhs.f_, reinterpret_cast<const double*>(rhs_multiplier.data())), lat_->ctx(),
                    "rescale_add");
     return *this;
   }
   block_fermion_field& rescale_add(const block_matrix<N_rhs>& lhs_multiplier, const block_fermion_field& rhs,
                                    const block_matrix<N_rhs>& rhs_multiplier) {
+    if (&rhs == this) return rescale_add(lhs_multiplier, block_fermion_field(rhs), rhs_multiplier);
     dev2(rhs);
     blockcg::check(bcg_field_rescale_add_matrix(f_, reinterpret_cast<const double*>(lhs_multiplier.data()), rhs.f_, 0.0),
                    lat_->ctx(), "rescale_add");

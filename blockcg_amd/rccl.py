@@ -17,6 +17,7 @@ UNIQUE_ID_BYTES = 128
 SIGNATURES = {
     "bcg_rccl_get_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_unique_id_via_file": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+    "bcg_rccl_unique_id_file_done": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]),
     "bcg_comm_rccl_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_comm_rccl_callbacks": (ctypes.POINTER(_lib.bcg_comm), [ctypes.c_void_p]),
@@ -33,6 +34,8 @@ def load():
     global _rlib
     if _rlib is None:
         _lib.load()  # libblockcg_hip.so first (and the one-time build on a fresh checkout)
+        if _lib.HIP_RUNTIME == "torch-bundle":  # keep RCCL on the same runtime instance as HIP (_lib.single_hip_runtime)
+            _lib.single_hip_runtime(extra=("librccl.so",))
         if not os.path.exists(LIB_PATH):
             _lib.build()
         lib = ctypes.CDLL(LIB_PATH)

@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "rank %d: %s\n", rank, bcg_rccl_last_error(nullptr));
       return 1;
     }
+    bcg_rccl_unique_id_file_done(argv[1], rank, comm);  // the rendezvous file is single-use: removed once all ranks are in
     if (ring > 0) blockcg::check(bcg_capacity_mode(lat.ctx(), ring), lat.ctx(), "bcg_capacity_mode");
 
     dirac_op D(lat, mass, /*seed=*/1);                         // benchmark.cpp:36

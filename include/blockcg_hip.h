@@ -27,7 +27,9 @@
  *    eta_mu(x) = (-1)^(x_0+...+x_{mu-1})  (global coordinates).
  *  - One context = one GPU = one rank of a process grid.  With grid = {1,1,1,1} nothing
  *    communicates.  With more ranks the caller supplies two callbacks (bcg_comm) that move halo
- *    faces and sum m x m partials; bench.py implements them with torch.distributed (RCCL).
+ *    faces and sum m x m partials.  libblockcg_rccl.so (include/blockcg_rccl.h) implements them natively on RCCL
+ *    (grouped ncclSend/ncclRecv, ncclAllReduce) -- what bench.py and examples/multi_gpu_solver.cpp use;
+ *    blockcg_amd/comm.py is a torch.distributed implementation kept for rehearsals (gloo: ranks sharing one GPU).
  *  - All work is enqueued on the context's HIP stream; calls that return host data synchronize it.
  */
 #ifndef BLOCKCG_HIP_H

@@ -36,6 +36,12 @@ int bcg_rccl_get_unique_id(void* id_bytes_out);
 /* File rendezvous for hosts without another channel: rank 0 creates the id and writes it to `path` (atomically, via a
  * temporary name); the other ranks poll for the file (up to timeout_s seconds).  All ranks return the same id. */
 int bcg_rccl_unique_id_via_file(const char* path, int rank, double timeout_s, void* id_bytes_out);
+/* The rendezvous is SINGLE-USE: once bcg_comm_rccl_create has returned on every rank, call this on every rank; it
+ * barriers over the communicator and rank 0 removes the file, so that the same path can serve the next launch.  A launch
+ * that died before this point leaves the file behind; a launcher therefore also exports a per-launch BCG_RUN_TOKEN
+ * (tools/launch_ranks.sh does): when that variable is set both functions use `path.<token>` instead of `path`, and a
+ * stale file of another launch is never read. */
+int bcg_rccl_unique_id_file_done(const char* path, int rank, bcg_rccl_comm* comm);
 /* ncclCommInitRank on the context's device, then bcg_context_set_comm(ctx, the RCCL callbacks).  Collective over all
  * `world` ranks.  world == 1 is allowed (the callbacks then only ever see messages to self). */
 int bcg_comm_rccl_create(bcg_context* ctx, const void* unique_id_bytes, int rank, int world, bcg_rccl_comm** out);

@@ -71,6 +71,28 @@ int main() {
     for (int x = 0; x < V; ++x) want[x] = y0[x] * M1 + b0[x] * M2;
     check("rescale_add(matrix, rhs, matrix)", T, want);
   }
+  {  // rhs == *this, every multiplier combination (the reference's templates accept it: inc/fields.hpp:70-90)
+    block_fermion_field<N> T(Y);
+    T.add(T, 0.3);
+    for (int x = 0; x < V; ++x) want[x] = y0[x] + 0.3 * y0[x];
+    check("add(*this, double)", T, want);
+    block_fermion_field<N> T2(Y);
+    T2.add(T2, M1);
+    for (int x = 0; x < V; ++x) want[x] = y0[x] + y0[x] * M1;
+    check("add(*this, matrix)", T2, want);
+    block_fermion_field<N> T3(Y);
+    T3.rescale_add(M1, T3, 0.5);
+    for (int x = 0; x < V; ++x) want[x] = y0[x] * M1 + 0.5 * y0[x];
+    check("rescale_add(matrix, *this, double)", T3, want);
+    block_fermion_field<N> T4(Y);
+    T4.rescale_add(0.6, T4, M2);
+    for (int x = 0; x < V; ++x) want[x] = 0.6 * y0[x] + y0[x] * M2;
+    check("rescale_add(double, *this, matrix)", T4, want);
+    block_fermion_field<N> T5(Y);
+    T5.rescale_add(M1, T5, M2);
+    for (int x = 0; x < V; ++x) want[x] = y0[x] * M1 + y0[x] * M2;
+    check("rescale_add(matrix, *this, matrix)", T5, want);
+  }
   {  // element write through operator[] reaches the device before the next device operation
     block_fermion_field<N> T(Y);
     T[5](1, 2) = blockcg::cplx(3.0, -4.0);

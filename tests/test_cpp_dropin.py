@@ -150,11 +150,13 @@ def test_unmodified_reference_unit_tests_pass_on_the_gpu():
 
 
 # ---- native multi-GPU driver (examples/multi_gpu_solver.cpp: drop-in headers + libblockcg_rccl.so, no Python) --------
-def _build_multi_gpu_driver():
+def _build_multi_gpu_driver(transport="blockcg_rccl"):
+    """transport = "blockcg_rccl_mock": the same driver linked against the test-only twin of the transport (several ranks
+    on one GPU)."""
     os.makedirs(OUT, exist_ok=True)
-    exe = os.path.join(OUT, "multi_gpu_solver")
+    exe = os.path.join(OUT, "multi_gpu_solver" + ("_mock" if transport.endswith("mock") else ""))
     cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-I", INC, os.path.join(ROOT, "examples", "multi_gpu_solver.cpp"),
-           "-o", exe, "-L", LIBDIR, "-lblockcg_rccl", "-lblockcg_hip", f"-Wl,-rpath,{LIBDIR}"]
+           "-o", exe, "-L", LIBDIR, f"-l{transport}", "-lblockcg_hip", f"-Wl,-rpath,{LIBDIR}"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe
@@ -179,6 +181,38 @@ def test_multi_gpu_driver_world_of_one(tmp_path):
         assert "SBCGrQ_iterations" in r.stdout
         res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
         assert len(res) == 4 and max(res) < 2e-9
+        assert not os.path.exists(idfile)  # the rendezvous file is single-use: rank 0 removed it
+
+
+@pytest.mark.gpu
+def test_multi_gpu_driver_two_ranks_same_idfile_twice(tmp_path):
+    """tools/launch_ranks.sh + the C++ driver with TWO ranks (both on GPU 0, over the host-staged stand-in for RCCL), run
+    twice with the SAME rendezvous path, the second time with a stale id file of a dead launch planted there: every launch
+    has its own run token, so the ranks of launch 2 cannot pick up an old id (they would wait for ever in the
+    communicator's initialisation), and each launch removes its own file."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "blockcg_amd", "csrc"), "-s", "mock"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = _build_multi_gpu_driver("blockcg_rccl_mock")
+    idfile = str(tmp_path / "bcg.id")
+    env = dict(os.environ, BCG_LOCAL_RANK_OVERRIDE="0", BCG_HOP_BLOCKS="8", BCG_HOP_PATCH="16,2,2")
+    iters = []
+    for launch in range(2):
+        if launch == 1:
+            with open(idfile, "wb") as f:
+                f.write(b"bcg_mock_stale_id".ljust(128, b"\0"))
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_ranks.sh"), "2", exe, idfile, "32", "4", "4", "8",
+                            "1", "1", "1", "2", "0.3", "1e-9"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
+        assert len(res) == 4 and max(res) < 2e-9
+        iters.append(int(re.search(r"SBCGrQ_iterations:\s+(\d+)", r.stdout).group(1)))
+        left = [f for f in os.listdir(tmp_path) if f.startswith("bcg.id.")]
+        assert not left, left
+    assert iters[0] == iters[1]
+    import glob
+    import shutil
+    for d in glob.glob("/dev/shm/bcg_mock_*"):
+        shutil.rmtree(d, ignore_errors=True)
 
 
 @pytest.mark.gpu
