@@ -141,6 +141,19 @@ class block_fermion_field:
             pass
 
     # host <-> device
+    def pinned_array(self):
+        """A (V, N_rhs, 3) complex128 array in pinned host memory (bcg_host_alloc): transfers to / from it run at the bus
+        rate with no staging copy.  Freed when the array (and every view of it) is garbage-collected."""
+        import ctypes
+        import weakref
+        n = self.V * self.N_rhs * 3 * 16
+        p = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.bcg_host_alloc(n, ctypes.byref(p)))
+        buf = (ctypes.c_char * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.complex128).reshape(self.V, self.N_rhs, 3)
+        weakref.finalize(buf, self.ctx.lib.bcg_host_free, p)
+        return a
+
     def upload(self, host):
         a = np.ascontiguousarray(host, dtype=np.complex128)
         if a.shape != (self.V, self.N_rhs, 3):
@@ -148,8 +161,11 @@ class block_fermion_field:
         self.ctx.check(self.ctx.lib.bcg_field_upload(self.h, _dp(a)))
         return self
 
-    def download(self):
-        a = np.empty((self.V, self.N_rhs, 3), dtype=np.complex128)
+    def download(self, out=None):
+        """out: an existing (V, N_rhs, 3) complex128 array to fill (e.g. a view of pinned memory from pinned_array)."""
+        a = np.empty((self.V, self.N_rhs, 3), dtype=np.complex128) if out is None else out
+        if a.shape != (self.V, self.N_rhs, 3) or a.dtype != np.complex128 or not a.flags.c_contiguous:
+            raise ValueError("download(out=...): expected a C-contiguous complex128 array of shape (V, N_rhs, 3)")
         self.ctx.check(self.ctx.lib.bcg_field_download(self.h, _dp(a)))
         return a
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <thread>
 
 #include "context.hpp"
 #include "kernels_mfma.hpp"
@@ -196,10 +197,107 @@ int upload_mat(bcg_context* c, const CMat& M, const double2** dev_out) {
 int ensure_staging(bcg_context* c, size_t bytes) {
   if (bytes <= c->staging_bytes) return BCG_OK;
   if (c->staging) (void)hipFree(c->staging);
+  for (int k = 0; k < 2; ++k) {
+    if (c->xfer_dev[k]) (void)hipFree(c->xfer_dev[k]);
+    if (c->xfer_pin[k]) (void)hipHostFree(c->xfer_pin[k]);
+    if (c->xfer_done[k]) (void)hipEventDestroy(c->xfer_done[k]);
+    if (c->xfer_stream[k]) (void)hipStreamDestroy(c->xfer_stream[k]);
+  }
   c->staging = nullptr;
   c->staging_bytes = 0;
   HIP_TRY(c, hipMalloc(&c->staging, bytes));
   c->staging_bytes = bytes;
+  return BCG_OK;
+}
+
+// ---- host <-> device transfer pipeline (bcg_field_upload / bcg_field_download) ---------------------------------------------
+// The reference keeps its fields in host memory and reads elements there (benchmark.cpp:61-63); the device layout is
+// [site][colour][rhs], the host layout [site][rhs][colour], so every transfer passes a conversion kernel.  Chunks of
+// kXferChunk bytes alternate between two streams, each with a device staging buffer: the conversion kernel of one chunk
+// runs while the other chunk is on the bus.  Host memory the runtime knows as pinned (bcg_host_alloc, hipHostMalloc,
+// hipHostRegister) is the DMA's source / target directly; pageable memory goes through two pinned buffers that host threads
+// fill or drain while the other chunk is in flight (one memcpy thread cannot keep up with the bus).
+constexpr size_t kXferChunk = static_cast<size_t>(64) << 20;
+
+int ensure_xfer(bcg_context* c, bool need_pinned) {
+  if (!c->xfer_stream[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->xfer_stream[k], hipStreamNonBlocking));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->xfer_done[k], hipEventDisableTiming));
+      HIP_TRY(c, hipMalloc(&c->xfer_dev[k], kXferChunk));
+    }
+    c->xfer_bytes = kXferChunk;
+  }
+  if (need_pinned && !c->xfer_pin[0])
+    for (int k = 0; k < 2; ++k) HIP_TRY(c, hipHostMalloc(&c->xfer_pin[k], kXferChunk, hipHostMallocDefault));
+  return BCG_OK;
+}
+
+void par_memcpy(void* dst, const void* src, size_t n) {
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = static_cast<int>(std::max(1u, std::min(8u, hw ? hw / 2 : 1u)));
+  if (nt == 1 || n < (static_cast<size_t>(4) << 20)) {
+    std::memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t each = ((n / nt) + 4095) & ~static_cast<size_t>(4095);
+  for (int t = 1; t < nt; ++t) {
+    const size_t o = each * t;
+    if (o >= n) break;
+    th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, std::min(each, n - o)); });
+  }
+  std::memcpy(dst, src, std::min(each, n));
+  for (auto& t : th) t.join();
+}
+
+bool host_is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary malloc'ed pointer is "invalid value" to the runtime: not an error here
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+int transfer_field(bcg_context* c, bcg_field* f, double* host, bool to_device) {
+  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
+  const bool direct = host_is_pinned(host);
+  BCG_TRY(ensure_xfer(c, !direct));
+  BCG_TRY(stream_sync(c));  // order against everything enqueued on the context's stream
+  const int64_t chunk = static_cast<int64_t>(c->xfer_bytes / site_bytes);
+  const int64_t V = c->lat.V;
+  const int64_t nchunks = (V + chunk - 1) / chunk;
+  char* const hb = reinterpret_cast<char*>(host);
+  auto sites_of = [&](int64_t i) { return std::min<int64_t>(chunk, V - i * chunk); };
+  for (int64_t i = 0; i < nchunks + 2; ++i) {
+    const int k = static_cast<int>(i & 1);
+    if (i >= 2) {  // chunk i - 2 used the same stream and buffers
+      HIP_TRY(c, hipEventSynchronize(c->xfer_done[k]));
+      if (!to_device && !direct) par_memcpy(hb + (i - 2) * chunk * site_bytes, c->xfer_pin[k], sites_of(i - 2) * site_bytes);
+    }
+    if (i >= nchunks) continue;
+    const int64_t n = sites_of(i);
+    hipStream_t s = c->xfer_stream[k];
+    char* const hchunk = hb + i * chunk * site_bytes;
+    double2* const dchunk = f->d + i * chunk * 3 * f->m;
+    if (to_device) {
+      const void* src = hchunk;
+      if (!direct) {
+        par_memcpy(c->xfer_pin[k], hchunk, n * site_bytes);
+        src = c->xfer_pin[k];
+      }
+      HIP_TRY(c, hipMemcpyAsync(c->xfer_dev[k], src, n * site_bytes, hipMemcpyHostToDevice, s));
+      bcg::launch_host_to_dev(s, f->m, c->xfer_dev[k], dchunk, n);
+      BCG_TRY(check_launch(c, "host_to_dev"));
+    } else {
+      bcg::launch_dev_to_host(s, f->m, dchunk, c->xfer_dev[k], n);
+      BCG_TRY(check_launch(c, "dev_to_host"));
+      HIP_TRY(c, hipMemcpyAsync(direct ? static_cast<void*>(hchunk) : c->xfer_pin[k], c->xfer_dev[k], n * site_bytes,
+                                hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->xfer_done[k], s));
+  }
   return BCG_OK;
 }
 
@@ -985,40 +1083,23 @@ int bcg_field_destroy(bcg_field* f) {
 
 int bcg_field_width(const bcg_field* f) { return f ? f->m : -1; }
 
+int bcg_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return BCG_ERR_INVALID;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? BCG_OK : BCG_ERR_HIP;
+}
+int bcg_host_free(void* p) { return !p || hipHostFree(p) == hipSuccess ? BCG_OK : BCG_ERR_HIP; }
+
 int bcg_field_upload(bcg_field* f, const double* host) {
   DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f || !host) return BCG_ERR_INVALID;
-  bcg_context* c = f->ctx;
-  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
-  const int64_t chunk = std::min<int64_t>(c->lat.V, 1 << 18);
-  BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
-  for (int64_t s0 = 0; s0 < c->lat.V; s0 += chunk) {
-    const int64_t n = std::min<int64_t>(chunk, c->lat.V - s0);
-    HIP_TRY(c, hipMemcpyAsync(c->staging, reinterpret_cast<const char*>(host) + s0 * site_bytes, n * site_bytes,
-                              hipMemcpyHostToDevice, c->stream));
-    bcg::launch_host_to_dev(c->stream, f->m, c->staging, f->d + s0 * 3 * f->m, n);
-    BCG_TRY(check_launch(c, "host_to_dev"));
-    BCG_TRY(stream_sync(c));
-  }
-  return BCG_OK;
+  return transfer_field(f->ctx, f, const_cast<double*>(host), /*to_device=*/true);
 }
 
 int bcg_field_download(const bcg_field* f, double* host) {
   DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f || !host) return BCG_ERR_INVALID;
-  bcg_context* c = f->ctx;
-  const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
-  const int64_t chunk = std::min<int64_t>(c->lat.V, 1 << 18);
-  BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
-  for (int64_t s0 = 0; s0 < c->lat.V; s0 += chunk) {
-    const int64_t n = std::min<int64_t>(chunk, c->lat.V - s0);
-    bcg::launch_dev_to_host(c->stream, f->m, f->d + s0 * 3 * f->m, c->staging, n);
-    BCG_TRY(check_launch(c, "dev_to_host"));
-    HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char*>(host) + s0 * site_bytes, c->staging, n * site_bytes,
-                              hipMemcpyDeviceToHost, c->stream));
-    BCG_TRY(stream_sync(c));
-  }
-  return BCG_OK;
+  return transfer_field(f->ctx, const_cast<bcg_field*>(f), host, /*to_device=*/false);
 }
 
 int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites, double* host) {

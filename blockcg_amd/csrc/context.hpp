@@ -69,8 +69,15 @@ struct bcg_context {
   int mat_slots = 0, mat_next = 0, mat_in_flight = 0;
   double2* dev_gram = nullptr;           // reduced Gram matrix (device), all-reduced in place
   double* pin_gram = nullptr;            // pinned host copy
-  double2* staging = nullptr;            // upload/download layout-conversion staging
+  double2* staging = nullptr;            // layout-conversion staging of bcg_field_download_sites
   size_t staging_bytes = 0;
+  // host <-> device pipeline of bcg_field_upload / bcg_field_download: two chunks in flight, each with its own stream,
+  // device staging buffer (layout conversion) and pinned host buffer (only used when the caller's memory is pageable)
+  hipStream_t xfer_stream[2] = {nullptr, nullptr};
+  hipEvent_t xfer_done[2] = {nullptr, nullptr};
+  double2* xfer_dev[2] = {nullptr, nullptr};
+  void* xfer_pin[2] = {nullptr, nullptr};
+  size_t xfer_bytes = 0;
 
   // profiling
   bool profiling = false;

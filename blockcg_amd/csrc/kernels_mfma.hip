@@ -41,6 +41,45 @@ __device__ __forceinline__ double2 ld_nt(const double2* p) {
   const dv2 v = __builtin_nontemporal_load(reinterpret_cast<const dv2*>(p));
   return make_double2(v.x, v.y);
 }
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per active lane from the lane's own global address straight into LDS at
+// `lds_dst` + 16 * lane (wave-uniform base in M0; no VGPR destination).  Written as asm so that hipcc does not see it:
+// it would otherwise wait vmcnt(0) at the next use of ANY ordinary load while one is in flight.  Consequences the callers
+// rely on: vector-memory operations complete in issue order, so once the wave has consumed an ordinary load issued AFTER
+// the DMA, the DMA has landed; nothing else orders a later ds_read behind it.
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_char_t*)p));
+}
+#ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
+#define BCG_HOP4B_ROWDMA 0
+#endif
+#ifndef BCG_HOP4B_STORE_SC1  // tuning builds: write-through output stores (the lines do not stay in the XCD's L2)
+#define BCG_HOP4B_STORE_SC1 0
+#endif
+#ifdef BCG_HOP4B_LINK_NT     // tuning builds: non-temporal link DMAs
+#define BCG_GLDS_LINK_AUX " nt"
+#else
+#define BCG_GLDS_LINK_AUX ""
+#endif
+__device__ __forceinline__ void glds16_link(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" BCG_GLDS_LINK_AUX
+               "\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst));
+}
+__device__ __forceinline__ void st_sc1(double2* p, double2 v) {
+  dv2 w;
+  w.x = v.x;
+  w.y = v.y;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w));
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst));  // no "memory" clobber: it would force the callers' captured state into scratch;
+}                                            // the block barriers around every use order it against the compiler's LDS accesses
 // link loads of the stencil (non-temporal loads were tried here: 13 % fewer L2 misses, no time gained)
 __device__ __forceinline__ dv2 ld_link(const dv2* p) { return *p; }
 __device__ __forceinline__ void st_nt(double2* p, double2 v) {
@@ -1438,10 +1477,19 @@ k_hop4c_interior(LatticeDev lat, const double2* __restrict__ U, const double2* _
 //     site instead of 8 (4.5 at m = 16), 19 vector-memory instructions per wave and tile instead of 31;
 //   * links are staged per wave for its own sites and parked at the END of the step, behind the last use of loaded
 //     data and in front of the output stores (see there);
+//   * backward links U_mu(x - mu) are NOT fetched again where the bundle already holds them: U_3(x - 3) is the wave's own
+//     forward link of the previous step and is carried from the old link image into the new one when the links are parked
+//     (fetched only in a column's prologue); U_1(x - 1) / U_2(x - 2) of a neighbour INSIDE the bundle are read from the
+//     partner wave's forward image (SHARE: two images per wave, written one step ahead, so that a faster partner never
+//     overwrites the image a slower wave still reads); only the rows that leave the bundle come from global memory;
 // Tile order, XCD patches, pacing, x3 windows and ring addressing (capacity mode) and the fused Gram product are those
 // of k_hop4c; the interior / boundary tile classes of the split halo exchange stay with k_hop4c.  Same arithmetic per site
 // and the same order of the four directions, so results are bit-identical to k_hop4c.
 // ---------------------------------------------------------------------------------------------------
+// Two link images per wave (partner waves read each other's forward links) where two blocks per CU still fit the 160 KB
+// of LDS: m = 16 (73.7 KB per block) and m = 32 (70 KB); at m = 8 (two images: 100 KB) one image, own links only.
+__host__ __device__ constexpr bool hop4b_share_images(int m) { return m >= 16; }
+
 template <int M, int MODE, bool GRAM, bool RING>
 __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2* __restrict__ U,
                                            const double2* __restrict__ Ughost, const double2* __restrict__ in,
@@ -1461,6 +1509,10 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   constexpr int LSTAGE = NFW + NBW;
   constexpr int RFW = (SPW * 36 + 63) / 64;
   constexpr int RBK = (SPW * 9 + 63) / 64;
+  constexpr bool SHARE = hop4b_share_images(M);
+  constexpr bool ROWDMA = BCG_HOP4B_ROWDMA != 0;  // +x3 row (own sites + halo sites) by LDS-DMA into its slot
+  constexpr int HB = 3 * M * 16;                  // bytes of one site = of one halo site
+  constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site  // in-bundle backward links from the partner waves' images (2 images per wave)
   constexpr int RB = 3 * M * 16;           // bytes of one site of a field
   constexpr int NH = (2 * M + 63) / 64;    // halo loads per lane and colour (1)
   static_assert(NH == 1, "halo sites fit one wave instruction per colour");
@@ -1469,9 +1521,12 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int e1 = wave & 1, e2 = wave >> 1;
   dv2* const Cbase = reinterpret_cast<dv2*>(smem);                       // [2 slots][4 waves][CS]
-  // this wave's link image: ONE copy suffices -- the next step's links wait in registers and are parked at the end of the
-  // step, behind the wave's last read of the image (LDS operations of a wave are in order)
-  dv2* const Lw = Cbase + 2 * NW * CS + wave * LSTAGE;
+  // Link images.  !SHARE: one per wave -- the next step's links wait in registers and are parked at the end of the step,
+  // behind the wave's last read of the image (LDS operations of a wave are in order).  SHARE: image x3 & 1 is read in
+  // step x3 by its wave AND by the two partner waves; the links of step x3 + 1 go into the other image, whose last
+  // readers (step x3 - 1) are behind the barrier at the top of step x3.
+  dv2* const Lbase = Cbase + 2 * NW * CS;
+  auto image = [&](int x3, int w) __attribute__((always_inline)) { return Lbase + ((SHARE ? (x3 & 1) : 0) * NW + w) * LSTAGE; };
   const int sw = lane / M, j = lane % M;
   const unsigned voff = static_cast<unsigned>((sw * 3 * M + j) * 16);   // byte offset of (site sw, colour 0, rhs j) in a row
   const int co = (sw + 1) * 3 * M + j;                                   // the same element in a row slot (colour c: + c*M)
@@ -1502,13 +1557,32 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   dv2 rf[RFW], rx, rb1[RBK], rb2[RBK], rb3[RBK];
   rx = dv2{0.0, 0.0};
   const unsigned fo = static_cast<unsigned>(lane) * 16;
-  unsigned bo_f[RBK], bo_g[RBK];
-#pragma unroll
-  for (int k = 0; k < RBK; ++k) {
-    const int e = lane + 64 * k;
-    bo_f[k] = static_cast<unsigned>((e / 9) * 36 + e % 9) * 16;
-    bo_g[k] = static_cast<unsigned>(e) * 16;
+  // byte offset of backward-link element e = lane + 64 k (site e / 9, entry e % 9) in a row of 36-entry site records
+  // (bo_f) and in a packed ghost face (bo_g).  Scalars, not arrays: a wave-uniform choice between two array elements made
+  // the compiler keep both arrays in scratch and select between their ADDRESSES.
+  static_assert(RBK <= 2, "backward-link elements per lane");
+  const unsigned bo_f0 = static_cast<unsigned>((lane / 9) * 36 + lane % 9) * 16;
+  const unsigned bo_f1 = static_cast<unsigned>(((lane + 64) / 9) * 36 + (lane + 64) % 9) * 16;
+  const unsigned bo_g0 = static_cast<unsigned>(lane) * 16, bo_g1 = static_cast<unsigned>(lane + 64) * 16;
+  const unsigned bo_d0 = bo_g0 - bo_f0, bo_d1 = bo_g1 - bo_f1;
+#define BO_F(k) ((k) == 0 ? bo_f0 : bo_f1)
+  // offset for a ghost face (G true) or a field row: written as "bo_f + (G ? delta : 0)" -- a select between the two
+  // variables themselves is turned into a select between their addresses, which keeps them in scratch
+#define BO_SEL(G, k) (BO_F(k) + ((G) ? ((k) == 0 ? bo_d0 : bo_d1) : 0u))
+#ifdef BCG_HOP4B_STAMPS  // diagnostic build (tools/hop_stamps.py 4b): where a step's cycles go, summed per wave
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = __builtin_amdgcn_s_memtime();
+#define BCG_STAMPB(i)                                  \
+  {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    const long long t_ = __builtin_amdgcn_s_memtime(); \
+    seg[i] += t_ - tlast;                              \
+    tlast = t_;                                        \
+    __builtin_amdgcn_sched_barrier(0);                 \
   }
+#else
+#define BCG_STAMPB(i)
+#endif
   bool pace = true;   // thread 0: still pacing against the other blocks of the XCD class
   const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;  // 0, unknown to the compiler (read_counter)
   unsigned seen1 = 0, seen2 = 0;
@@ -1551,7 +1625,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #undef BCG_BACK_DIR
     const bool row_end = x0b + SPW == L0, row_start = x0b == 0;
 
-    auto fetch_links = [&](int x3) __attribute__((always_inline)) {
+    auto fetch_links = [&](int x3, bool first) __attribute__((always_inline)) {
       const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;  // the wave's first site
       const char* const fsrc = reinterpret_cast<const char*>(U) + sw0 * (36 * 16);
       const char* lsrc;  // U_0 of the site to the left of the wave's first site
@@ -1576,13 +1650,22 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
       for (int k = 0; k < RBK; ++k)
         if (lane + 64 * k < SPW * 9) {
-          rb1[k] = ld_link(reinterpret_cast<const dv2*>(q1 + (k_b1 ? bo_g[k] : bo_f[k])));
-          rb2[k] = ld_link(reinterpret_cast<const dv2*>(q2 + (k_b2 ? bo_g[k] : bo_f[k])));
-          rb3[k] = ld_link(reinterpret_cast<const dv2*>(q3 + (k_b3 ? bo_g[k] : bo_f[k])));
+          if (!SHARE || !e1) rb1[k] = ld_link(reinterpret_cast<const dv2*>(q1 + BO_SEL(k_b1, k)));
+          if (!SHARE || !e2) rb2[k] = ld_link(reinterpret_cast<const dv2*>(q2 + BO_SEL(k_b2, k)));
+          if (first) rb3[k] = ld_link(reinterpret_cast<const dv2*>(q3 + BO_SEL(k_b3, k)));
         }
     };
-    auto park_links = [&]() __attribute__((always_inline)) {
-      dv2* const Lf = Lw;
+    // Park the fetched links of slice x3 in image(x3).  first: a column's prologue (U_3(x - 3) fetched); otherwise U_3(x - 3)
+    // is U_3 of the wave's own sites in the image of slice x3 - 1, read here before that image (!SHARE: the same one) is
+    // overwritten -- LDS operations of a wave execute in order.
+    auto park_links = [&](int x3, bool first) __attribute__((always_inline)) {
+      dv2* const Lf = image(x3, wave);
+      if (!first) {
+        const dv2* const Lo = image(x3 - 1, wave);
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) rb3[k] = Lo[36 + 27 + (BO_F(k) >> 4)];
+      }
 #pragma unroll
       for (int k = 0; k < RFW; ++k)
         if (lane + 64 * k < SPW * 36) Lf[36 + lane + 64 * k] = rf[k];
@@ -1590,10 +1673,61 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
       for (int k = 0; k < RBK; ++k)
         if (lane + 64 * k < SPW * 9) {
-          Lf[NFW + lane + 64 * k] = rb1[k];
-          Lf[NFW + SPW * 9 + lane + 64 * k] = rb2[k];
+          if (!SHARE || !e1) Lf[NFW + lane + 64 * k] = rb1[k];
+          if (!SHARE || !e2) Lf[NFW + SPW * 9 + lane + 64 * k] = rb2[k];
           Lf[NFW + 2 * SPW * 9 + lane + 64 * k] = rb3[k];
         }
+    };
+    // SHARE: the links of slice x3 by LDS-DMA straight into image(x3) -- no staging registers, no ds_write.  Issued at the
+    // top of step x3 - 1 (the image's last readers, step x3 - 2, are behind that step's barrier), in FRONT of the step's
+    // ordinary loads: those are consumed inside the step, so the DMAs have landed before the wave reaches the next barrier.
+    // U_3(x - 3) is not fetched (first: it is, in a column's prologue): park_u3 carries it over.
+    auto dma_links = [&](int x3, bool first) __attribute__((always_inline)) {
+      const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
+      const char* const fsrc = reinterpret_cast<const char*>(U) + sw0 * (36 * 16);
+      const char* lsrc;
+      if (!row_start) lsrc = reinterpret_cast<const char*>(U) + (sw0 - 1) * (36 * 16);
+      else if (!sp0) lsrc = reinterpret_cast<const char*>(U) + (sw0 + L0 - 1) * (36 * 16);
+      else lsrc = reinterpret_cast<const char*>(Ughost) + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + L2 * x3))) * (9 * 16);
+      const unsigned img = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave)));
+#pragma unroll
+      for (int k = 0; k < RFW; ++k)
+        if (lane + 64 * k < SPW * 36) glds16_link(fsrc + fo + k * 1024, img + (36 + 64 * k) * 16);
+      if (lane < 9) glds16_link(lsrc + fo, img);
+      const char* const ub_ = reinterpret_cast<const char*>(U);
+      const char* const ug_ = reinterpret_cast<const char*>(Ughost);
+      if (!e1) {
+        const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(x3) * s_b1;
+        const char* const q1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) glds16_link(q1 + BO_SEL(k_b1, k), img + (NFW + 64 * k) * 16);
+      }
+      if (!e2) {
+        const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(x3) * s_b2;
+        const char* const q2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) glds16_link(q2 + BO_SEL(k_b2, k), img + (NFW + SPW * 9 + 64 * k) * 16);
+      }
+      if (first) {
+        const char* q3;
+        bool k_b3 = false;
+        if (x3 > 0) q3 = ub_ + ((sw0 - S3) * 4 + 3) * (9 * 16);
+        else if (!sp3) q3 = ub_ + ((sw0 + static_cast<int64_t>(L3 - 1) * S3) * 4 + 3) * (9 * 16);
+        else { q3 = ug_ + (static_cast<int64_t>(gm3) + col) * (9 * 16); k_b3 = true; }
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) glds16_link(q3 + BO_SEL(k_b3, k), img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
+      }
+    };
+    // U_3(x - 3) of slice x3 = U_3 of the wave's own sites in image(x3 - 1): copied into image(x3)
+    auto park_u3 = [&](int x3) __attribute__((always_inline)) {
+      const dv2* const Lo = image(x3 - 1, wave);
+      dv2* const Ln = image(x3, wave);
+#pragma unroll
+      for (int k = 0; k < RBK; ++k)
+        if (lane + 64 * k < SPW * 9) Ln[NFW + 2 * SPW * 9 + lane + 64 * k] = Lo[36 + 27 + (BO_F(k) >> 4)];
     };
     // Row `xs` of this wave's column as stored (slice index, or ring slot), with its two halo sites, `gx3` the slice's true
     // index (ghost faces keep whole-lattice indexing): pointers of the own sites and, per lane, of the halo site.
@@ -1614,6 +1748,22 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       } else {
         own = ghb + (static_cast<int64_t>(kind == 1 ? gp3 : gm3) + col) * RB;
         hal = own + hj * 16;  // any valid address: this row is never used as a centre row
+      }
+    };
+    // the same row for the DMA form: base pointers of the own sites and of the left / right halo site
+    auto row_ptrs3 = [&](int kind, int xs, int gx3, const char*& own, const char*& lft, const char*& rgt) __attribute__((always_inline)) {
+      if (kind == 0) {
+        own = inb + (static_cast<int64_t>(col) + static_cast<int64_t>(xs) * S3) * RB;
+        const int64_t f0i = x1 + L1 * (x2 + static_cast<int64_t>(L2) * gx3);
+        if (!row_start) lft = own - RB;
+        else if (!sp0) lft = own + static_cast<int64_t>(L0 - 1) * RB;
+        else lft = ghb + (static_cast<int64_t>(gm0) + f0i) * RB;
+        if (!row_end) rgt = own + static_cast<int64_t>(SPW) * RB;
+        else if (!sp0) rgt = own - static_cast<int64_t>(L0 - SPW) * RB;
+        else rgt = ghb + (static_cast<int64_t>(gp0) + f0i) * RB;
+      } else {
+        own = ghb + (static_cast<int64_t>(kind == 1 ? gp3 : gm3) + col) * RB;
+        lft = rgt = own;  // any valid address: this row is never used as a centre row
       }
     };
     // which stored slice / ghost face is slice g of the column (g may be -1 or L3: periodic image or ghost)
@@ -1649,8 +1799,13 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       dv2* const Cm = Cbase + (((lo + 1) & 1) * NW + wave) * CS;
 #pragma unroll
       for (int c = 0; c < 3; ++c) Cm[co + c * M] = *reinterpret_cast<const dv2*>(own + voff + c * M * 16);
-      fetch_links(lo);
-      park_links();
+      if (SHARE) {
+        dma_links(lo, true);
+        asm volatile("s_waitcnt vmcnt(0)");  // landed before the first step's barrier (hipcc does not count them)
+      } else {
+        fetch_links(lo, true);
+        park_links(lo, true);
+      }
     }
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
       const int step_n = vs0 + x3;
@@ -1669,16 +1824,45 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           }
         }
       }
+      BCG_STAMPB(0)   // pacing wait of thread 0 (the other waves' share of it shows up in the barrier)
       __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
-      if (x3 + 1 < x3_end) fetch_links(x3 + 1);  // parked at the end of this step
-      const dv2* const Lf = Lw;
+      BCG_STAMPB(1)   // barrier
+      if (x3 + 1 < x3_end) {
+        if (SHARE) dma_links(x3 + 1, false);   // into the other image, in front of this step's ordinary loads
+        else fetch_links(x3 + 1, false);       // parked at the end of this step
+      }
+      const dv2* const Lf = image(x3, wave);
       const dv2* const Lb = Lf + NFW;
+      // backward links of directions 1, 2: own image (row outside the bundle) or the partner wave's forward links
+      const dv2* const ub1 = (SHARE && e1) ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
+      const dv2* const ub2 = (SHARE && e2) ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
       const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;       // centre rows of the four waves (this slice)
       dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;  // this wave's slot for slice x3 + 1; holds slice x3 - 1
       double2 f[4][3], bk[4][3];
       // -x3 neighbour: this wave's own row of slice x3 - 1, read back before the slot is overwritten below
 #pragma unroll
       for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; bk[3][c] = make_double2(v.x, v.y); }
+      if (ROWDMA) {
+        // The +x3 row goes straight into Cn by LDS-DMA, so the old contents must be in registers first (the operands make
+        // the compiler wait for the three reads).  Issued in FRONT of the step's ordinary loads: those return in issue
+        // order behind it, so "o1[0] has arrived" (below) means the row has landed.
+        asm volatile("" : "+v"(bk[3][0].x), "+v"(bk[3][0].y), "+v"(bk[3][1].x), "+v"(bk[3][1].y), "+v"(bk[3][2].x), "+v"(bk[3][2].y));
+        int kind, xs, gx3;
+        const char* own;
+        const char* lft;
+        const char* rgt;
+        slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
+        row_ptrs3(kind, xs, gx3, own, lft, rgt);
+        const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(Cn));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) glds16(own + fo + k * 1024, cn + HB + k * 1024);  // SPW sites = 3 KB at every width
+#pragma unroll
+        for (int k = 0; k < NHD; ++k)
+          if (lane * 16 + k * 1024 < HB) {
+            glds16(lft + fo + k * 1024, cn + k * 1024);
+            glds16(rgt + fo + k * 1024, cn + (SPW + 1) * HB + k * 1024);
+          }
+      }
       // ---- global loads of the step: the two rows that leave the bundle, the +x3 row with its halo, p
       const char* const q_o1 = (k_o1 ? ghb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(x3) * s_o1) * RB
                                      : inb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(RING_IN ? slot : x3) * s_o1) * RB);
@@ -1690,7 +1874,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
       for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
       dv2 hv[3];
-      {
+      if (!ROWDMA) {
         int kind, xs, gx3;
         const char* own;
         const char* hal;
@@ -1714,6 +1898,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
         for (int r = 0; r < 3; ++r) bv[r] = ld_nt(reinterpret_cast<const double2*>(orow + voff + r * M * 16));
       }
+      BCG_STAMPB(2)   // issue of the step's DMAs and loads
       // ---- neighbours inside the bundle, from the row slots: x0 (own row shifted by a site), x1 and x2 (partner waves)
       const dv2* const Cown = Cc + wave * CS;
       const dv2* const Cp1 = Cc + (wave ^ 1) * CS;
@@ -1744,10 +1929,17 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
         __builtin_amdgcn_sched_barrier(0);
+        if (ROWDMA && mu == 3) {
+          // o1[0] is the oldest ordinary load of the step and younger than the row DMAs: once it is in its register the row
+          // is in Cn; the clobber keeps the compiler from reading Cn earlier (or re-using bk[3], read from the same address)
+          asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y) : : "memory");
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; f[3][c] = make_double2(v.x, v.y); }
+        }
         const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
         const double eta = (par & 1) ? -1.0 : 1.0;
         const dv2* uf = Lf + (sw + 1) * 36 + mu * 9;
-        const dv2* ub = mu == 0 ? Lf + sw * 36 : Lb + ((mu - 1) * SPW + sw) * 9;
+        const dv2* ub = mu == 0 ? Lf + sw * 36 : (mu == 1 ? ub1 : (mu == 2 ? ub2 : Lb + (2 * SPW + sw) * 9));
         double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1769,20 +1961,28 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         // pin this direction's arithmetic here: the compiler otherwise sinks FMAs past the branches below, towards the
         // stores, and the link entries they read stay live across them
         asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y));
+#ifdef BCG_HOP4B_STAMPS
+        if (mu == 0) BCG_STAMPB(3) else if (mu == 1) BCG_STAMPB(4) else if (mu == 2) BCG_STAMPB(5) else BCG_STAMPB(6)
+#endif
       }
       // Every load of this step has been consumed, so parking the next step's links (an `s_waitcnt vmcnt(0)` in front of
       // the LDS writes: the compiler cannot count across the step's branches) drains nothing.  The output stores and the
       // pacing atomics are issued behind it and are never waited for inside the step: k_hop4c parks at the top of the
       // next tile and drains them there, 13 % of its time.
-      if (x3 + 1 < x3_end) park_links();
+      if (x3 + 1 < x3_end) {
+        if (SHARE) park_u3(x3 + 1);
+        else park_links(x3 + 1, false);
+      }
       // park the +x3 row (own sites and halo) as the next step's centre row
+      if (!ROWDMA) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        dv2 v;
-        v.x = f[3][c].x;
-        v.y = f[3][c].y;
-        Cn[co + c * M] = v;
-        if (halo_lane) Cn[ho + c * M] = hv[c];
+        for (int c = 0; c < 3; ++c) {
+          dv2 v;
+          v.x = f[3][c].x;
+          v.y = f[3][c].y;
+          Cn[co + c * M] = v;
+          if (halo_lane) Cn[ho + c * M] = hv[c];
+        }
       }
       double2 tv[3];
 #pragma unroll
@@ -1790,6 +1990,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
         if (RESID) tv[r] = make_double2(tv[r].x - bv[r].x, tv[r].y - bv[r].y);  // AX -= B (test/solvers.cpp:109)
+        else if (BCG_HOP4B_STORE_SC1) st_sc1(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
         else st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
       }
       if (GRAM) {
@@ -1806,12 +2007,22 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
       }
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+      BCG_STAMPB(7)   // tail: links/row parked, p, stores, pacing counters
     }
   }
+#ifdef BCG_HOP4B_STAMPS
+  if (!GRAM && lane == 0) {
+    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = static_cast<double>(seg[i]);
+  }
+#endif
+#undef BCG_STAMPB
   if (GRAM) {
     if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
     else gram_block_store<16, NW>(G, smem, partials, tid);
   }
+#undef BO_F
+#undef BO_SEL
 }
 
 template <int M, int MODE, bool GRAM, bool RING>
@@ -2087,7 +2298,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
     constexpr int SPW = 64 / M;
-    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPW + 2) * 3 * M) + 4 * ((SPW + 1) * 36 + 3 * SPW * 9));
+    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPW + 2) * 3 * M) +
+                                            (hop4b_share_images(M) ? 2 : 1) * 4 * ((SPW + 1) * 36 + 3 * SPW * 9));
     const size_t lds = lds_u > lds_g ? lds_u : lds_g;
 #define BCG_LAUNCH4B(MM, MD, GR, RG)                                                                                \
   do {                                                                                                             \

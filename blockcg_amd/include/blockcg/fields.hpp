@@ -50,6 +50,32 @@ class rand_state_guard {
   char* prev_;
 };
 
+// Allocator of the host mirror behind operator[]: pinned memory (bcg_host_alloc), so that a whole-field download or
+// upload runs at the bus rate straight into / out of the mirror; elements are NOT value-initialised on resize (the
+// mirror is always filled by a download or by setRandom before it is read).
+template <class T>
+struct pinned_allocator {
+  typedef T value_type;
+  pinned_allocator() {}
+  template <class U>
+  pinned_allocator(const pinned_allocator<U>&) {}
+  T* allocate(std::size_t n) {
+    void* p = nullptr;
+    rand_state_guard keep_callers_rand_sequence;  // the runtime may draw from rand() (see rand_state_guard)
+    if (bcg_host_alloc(n * sizeof(T), &p) != BCG_OK || !p) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, std::size_t) { bcg_host_free(p); }
+  template <class U>
+  void construct(U*) {}  // default-initialisation: leave the bytes as they are
+  template <class U, class... A>
+  void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(static_cast<A&&>(a)...); }
+  template <class U>
+  bool operator==(const pinned_allocator<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const pinned_allocator<U>&) const { return false; }
+};
+
 // One GPU's (sub-)lattice: owns the bcg_context.
 class lattice {
  public:
@@ -258,7 +284,7 @@ class block_fermion_field {
   }
   blockcg::lattice* lat_;
   bcg_field* f_ = nullptr;
-  mutable std::vector<block_fermion<N_rhs>> host_;
+  mutable std::vector<block_fermion<N_rhs>, blockcg::pinned_allocator<block_fermion<N_rhs>>> host_;
   mutable bool host_valid_ = false, host_dirty_ = false;
 };
 typedef block_fermion_field<1> fermion_field;  // :148

@@ -134,8 +134,17 @@ int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int con
 int bcg_field_create(bcg_context* ctx, int m, bcg_field** f);          /* explicit ctor :35 (contents undefined) */
 int bcg_field_destroy(bcg_field* f);
 int bcg_field_width(const bcg_field* f);
-int bcg_field_upload(bcg_field* f, const double* host);                 /* host -> device, layout conversion */
+/* The reference's fields live in host memory in the layout [site][rhs][colour] (inc/fields.hpp:19-20,28-30) and its
+ * drivers read elements there (benchmark.cpp:61-63).  Both transfers convert the layout on the device and pipeline two
+ * chunks (conversion kernel of one behind the bus transfer of the other).  Host memory the HIP runtime knows as pinned --
+ * bcg_host_alloc below, hipHostMalloc, hipHostRegister -- is read / written by the DMA engine directly; pageable memory
+ * goes through two pinned staging buffers that several host threads fill / drain. */
+int bcg_field_upload(bcg_field* f, const double* host);                 /* host -> device */
 int bcg_field_download(const bcg_field* f, double* host);               /* device -> host */
+/* Pinned host memory for such mirrors (std::vector's allocator in the reference: Eigen::aligned_allocator,
+ * inc/fields.hpp:28-30); no context needed. */
+int bcg_host_alloc(size_t bytes, void** out);
+int bcg_host_free(void* p);
 /* operator[](int) :37-38 read access without moving the whole field: the tiles of n chosen LOCAL sites,
  * host[k] = f[sites[k]] in the host layout ([rhs][colour], 48*m bytes each).  Sites out of range: BCG_ERR_INVALID. */
 int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites, double* host);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Tuning aid (GPU box): where the cycles of a stencil tile go (k_hop4c, plain form), from in-kernel s_memtime stamps.
-Needs a library built with -DBCG_HOP4C_STAMPS (tools/build_variant.sh stamps "-DBCG_HOP4C_STAMPS"; BCG_LIB=...)."""
+"""Tuning aid (GPU box): where the cycles of a stencil tile go (plain form), from in-kernel s_memtime stamps.
+k_hop4c: library built with -DBCG_HOP4C_STAMPS and BCG_HOP_BUNDLE=0; k_hop4b (the default form): -DBCG_HOP4B_STAMPS and
+`python tools/hop_stamps.py 4b`  (tools/build_variant.sh stamps "-DBCG_HOP4B_STAMPS"; BCG_LIB=...)."""
 import ctypes
 import os
 import sys
@@ -31,6 +32,8 @@ assert lib.bcg_debug_read_scratch(ctx.h, buf.ctypes.data_as(ctypes.c_void_p), bu
 seg = buf.reshape(nblk, 4, 8)
 tiles = 64 ** 4 // 16 // nblk
 names = ["park+pace", "barrier", "issue(links,dir0)", "dir0", "dir1", "dir2", "dir3(+x3)", "tail(p,store)"]
+if len(sys.argv) > 1 and sys.argv[1] == "4b":
+    names = ["pace(thread 0)", "barrier", "issue(DMAs,loads)", "dir0 (LDS only)", "dir1 (+wait loads)", "dir2", "dir3", "tail(park,store)"]
 tot = seg.sum(axis=2)
 print("cycles per tile per wave (s_memtime ticks = shader cycles): total median %.0f" % np.median(tot / tiles))
 for i, n in enumerate(names):

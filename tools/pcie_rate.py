@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: host <-> device rate of the boundary's layout-converting upload / download (bcg_field_upload/download),
-for the PCIe-inclusive note in DESIGN.md section 6.  64^3 x 16 sites, m = 16 (3.2 GB per field)."""
+for the PCIe-inclusive note in DESIGN.md section 6.  64^3 x 16 sites, m = 16 (3.2 GB per field); pageable host memory
+(touched beforehand: first-touch page faults are the allocator's cost, not the transfer's) and pinned host memory
+(bcg_host_alloc: what the C++ headers' operator[] mirror uses).  Prints one JSON line."""
+import json
 import os
 import sys
 import time
@@ -12,15 +15,29 @@ import blockcg_amd as bc  # noqa: E402
 
 dims, m = [64, 64, 64, 16], 16
 ctx = bc.Context(dims)
-f = bc.block_fermion_field(ctx, m)
-h = np.zeros((ctx.V, m, 3), dtype=np.complex128)
-h[:] = 1.0
-nbytes = h.nbytes
-for name, fn in (("upload", lambda: f.upload(h)), ("download", lambda: f.download())):
-    fn()
-    ctx.synchronize()
+f = bc.block_fermion_field(ctx, m).setRandom(seed=3)
+g = bc.block_fermion_field(ctx, m)
+out = {"sites": ctx.V, "m": m}
+ref = None
+for kind in ("pageable", "pinned"):
     t = time.perf_counter()
-    fn()
-    ctx.synchronize()
-    dt = time.perf_counter() - t
-    print(f"{name}: {nbytes / 1e9:.2f} GB in {dt * 1e3:.1f} ms = {nbytes / dt / 1e9:.1f} GB/s (pageable host memory, staged, layout-converted)")
+    h = np.empty((ctx.V, m, 3), dtype=np.complex128) if kind == "pageable" else f.pinned_array()
+    h[:] = 1.0
+    out[f"{kind}_alloc_and_touch_s"] = round(time.perf_counter() - t, 3)
+    nbytes = h.nbytes
+    for name, fn in (("download", lambda: f.download(out=h)), ("upload", lambda: g.upload(h))):
+        fn()
+        ctx.synchronize()
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            fn()
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t)
+        out[f"{kind}_{name}_GBps"] = round(nbytes / best / 1e9, 1)
+    # round trip is exact: g now holds what f holds
+    if ref is None:
+        ref = h[::4099].copy()
+    assert np.array_equal(h[::4099], ref) and np.array_equal(g.download()[::4099], ref), kind
+out["bytes"] = nbytes
+print(json.dumps(out))
