@@ -7,7 +7,8 @@ Workload at N = 1: BASELINE.json configs[2], V = 64^4, m = 16 right-hand sides, 
 the largest configuration that fits one GPU (128^4 needs 2.4 TB).
 
 N > 1 is the ladder that ends at the BASELINE headline, configs[3] (V = 128^4, m = 16, 4 shifts on 8 GPUs): every
-GPU holds 64 x 64 x 64 x 128 sites (281 GB of the 288 GiB, capacity mode with a ring of 16 x3-slices) and the process
+GPU holds 64 x 64 x 64 x 128 sites (capacity mode with a ring of 32 x3-slices: 15-slice chunks whose face exchanges
+overlap the stencil work on the neighbouring chunks; 287 GB planned of the 288 GiB = 309 GB) and the process
 grid grows over x2, x1, x0 with x3 undivided:
     N = 2: 64 x 64 x 128 x 128 (grid 1,1,2,1)   N = 4: 64 x 128 x 128 x 128 (1,2,2,1)   N = 8: 128^4 (2,2,2,1)
 `python bench.py --gpus N` starts its N ranks itself (fresh child processes under torch.distributed.run, before this
@@ -164,7 +165,9 @@ def resolve_shape(world, local_dims, capacity):
     if local_dims is None:
         local_dims = [64, 64, 64, 128] if world > 1 else [64, 64, 64, 64]
     if capacity is None:
-        capacity = 16 if ladder else 0  # measured on one GPU at this share: ring 16 140.4 ms, ring 8 142.6-144.6 ms per iteration
+        # ring 32: with the per-chunk exchanges overlapped the ring holds two chunks (C = 15 slices: the bundle form of the
+        # stencil needs windows of >= 10); measured on one GPU at this share, serial form: ring 16 139.5 ms, ring 8 142.5 ms
+        capacity = 32 if ladder else 0
     return list(local_dims), capacity, ladder
 
 
@@ -182,7 +185,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=None, metavar="R",
                     help="capacity mode: keep the operator's intermediate field as a ring of R x3 slices "
                          "(bcg_capacity_mode); the process grid then leaves x3 undivided "
-                         "(default: 0 on one GPU, 16 on several with the default shape)")
+                         "(default: 0 on one GPU, 32 on several with the default shape)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
@@ -328,7 +331,7 @@ def main():
             "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
                                    f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)"
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
-                                      "(64^3x128 per GPU, capacity ring 16)" if default_shape else ""),
+                                      "(64^3x128 per GPU, capacity ring 32)" if default_shape else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
             "iterations_per_sec": its,
             "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,

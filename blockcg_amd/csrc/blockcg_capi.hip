@@ -160,6 +160,10 @@ int ensure_scratch(bcg_context* c) {
     HIP_TRY(c, hipMalloc(&c->hop_tune.sync.counters, sizeof(unsigned) * 8 * kSyncStride));
     c->hop_tune.sync.stride = kSyncStride;
   }
+  if (!c->fold_tickets) {
+    HIP_TRY(c, hipMalloc(&c->fold_tickets, 16 * sizeof(unsigned)));
+    HIP_TRY(c, hipMemsetAsync(c->fold_tickets, 0, 16 * sizeof(unsigned), c->stream));
+  }
   if (!c->dev_gram) {
     HIP_TRY(c, hipMalloc(&c->dev_gram, kMatSlotBytes));
     HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin_gram), kMatSlotBytes, hipHostMallocDefault));
@@ -401,7 +405,7 @@ int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
 
 // Faces of the x3 slices [x3_lo, x3_lo + x3_n) only; `d` is a whole field (ring = 0) or a ring of slices (capacity mode).
 // The other slices' ranges of the ghost buffer keep what they held.
-int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring) {
+int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring, bool split = false) {
   if (!c->distributed) return BCG_OK;
   const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
   BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
@@ -410,8 +414,37 @@ int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, in
     bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3_lo, x3_n, ring);
   }
   BCG_TRY(check_launch(c, "pack_faces"));
-  ProfScope ps(c, "halo_exchange");
-  return exchange_faces(c, site_bytes, false, x3_lo, x3_n);
+  ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
+  return exchange_faces(c, site_bytes, split, x3_lo, x3_n);
+}
+
+// Capacity mode with overlapped exchanges: the received faces of slice x3 = 0 of every split direction, saved aside
+// (save) or put back (!save).  The ghost ranges of slice 0 are re-used for the faces of `tmp` while the source's faces of
+// that slice are needed once more at the end of the sweep (apply_shifted_ring).
+int slice0_faces(bcg_context* c, size_t site_bytes, bool save) {
+  int peer_s[8], peer_r[8];
+  size_t off_s[8], off_r[8], nb[8];
+  const int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
+  if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) total += nb[k] / c->lat.L[3];
+  if (total > c->halo_save_bytes) {
+    BCG_TRY(stream_sync(c));
+    if (c->halo_save) (void)hipFree(c->halo_save);
+    c->halo_save = nullptr;
+    c->halo_save_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->halo_save, total));
+    c->halo_save_bytes = total;
+  }
+  size_t at = 0;
+  for (int k = 0; k < n; ++k) {
+    const size_t each = nb[k] / c->lat.L[3];
+    char* const ghost = reinterpret_cast<char*>(c->halo_recv) + off_r[k];
+    char* const keep = reinterpret_cast<char*>(c->halo_save) + at;
+    HIP_TRY(c, hipMemcpyAsync(save ? keep : ghost, save ? ghost : keep, each, hipMemcpyDeviceToDevice, c->stream));
+    at += each;
+  }
+  return BCG_OK;
 }
 
 int halo_gauge(bcg_context* c, bcg_gauge* g) {
@@ -477,10 +510,11 @@ void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWind
 // out = D in  (HOP_PLAIN)  or  out = c0*p - D in  (HOP_SHIFTED).  With gram_blocks != nullptr (m = 16 fast
 // path, HOP_SHIFTED) the kernel also leaves block partials of p^dagger out in c->partials.
 int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
-        double c0, int* gram_blocks = nullptr) {
+        double c0, int* gram_blocks = nullptr, bool* gram_folded = nullptr) {
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
   const int m = in->m;
   if (gram_blocks) *gram_blocks = 0;
+  if (gram_folded) *gram_folded = false;
   const bool fast = fast_hop(c, m);
   // fused Gram product: m = 16 in every form of the specialised stencil; m = 8 in the column-sweep kernel, one launch
   const bool split_path = fast && bcg::hop_can_split_tiles(m, c->lat) && can_overlap(c);
@@ -526,10 +560,15 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   BCG_TRY(halo_field(c, in));
   if (fast) {
     note_stencil_form(c, m, 0, bcg::HopWindow(), mode == bcg::HOP_PLAIN);
+    bcg::HopTuning tune = c->hop_tune;
+    // one whole launch of a column form: the kernel's last blocks sum the Gram partials themselves (no reduction launch)
+    const bool fold = gram && gram_folded && bcg::hop_folds_gram(m, c->lat, kFastBlocks, tune, bcg::HopWindow());
+    if (fold) tune.fold = bcg::GramFold{c->dev_gram, c->fold_tickets};
     ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
-                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, c->hop_tune, 0);
+                                        p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, 0);
     if (gram) *gram_blocks = nb;
+    if (fold) *gram_folded = true;
   } else {
     ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
     bcg::launch_hop_generic(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
@@ -540,8 +579,9 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
 
 // Block partials in c->partials -> G (m x m), summed over blocks in a fixed order and over ranks,
 // Hermitian-mirrored exactly as inc/fields.hpp:115-120.
-int finish_gram(bcg_context* c, int m, int nblocks, CMat& G, bool mirror) {
-  {
+// folded: the producing kernel has already summed them into c->dev_gram (bcg::GramFold)
+int finish_gram(bcg_context* c, int m, int nblocks, CMat& G, bool mirror, bool folded = false) {
+  if (!folded) {
     ProfScope ps(c, "reduce_partials");
     bcg::launch_reduce_partials(c->stream, m * m, nblocks, c->partials, c->dev_gram);
   }
@@ -631,7 +671,12 @@ bool capacity_path(const bcg_context* c, int m) {
 }
 int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
                        int* gram_blocks) {
-  const int m = P->m, R = c->tmp_ring, C = R - 2, L3 = c->lat.L[3];
+  const int m = P->m, R = c->tmp_ring, L3 = c->lat.L[3];
+  // Overlapped form (ranks that exchange faces, split callbacks present, ring of at least 2 C + 2 slices): the exchange of
+  // chunk k's tmp faces runs while the first stencil works on chunk k + 1 and the second one on chunk k - 1, so the ring
+  // holds two chunks and the two boundary slices.  Otherwise C = R - 2 and every exchange is waited for where it is posted.
+  const bool overlap = c->ring_overlap && can_overlap(c) && (R - 2) / 2 >= 1;
+  const int C = overlap ? (R - 2) / 2 : R - 2;
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
   double2*& ring = c->tmp_ring_buf[m];
   if (!ring) HIP_TRY(c, hipMalloc(&ring, static_cast<size_t>(R) * c->lat.stride[3] * 3 * m * sizeof(double2)));
@@ -650,7 +695,9 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     HIP_TRY(c, hipMalloc(&c->partials, need));
     c->partials_bytes = need;
   }
+  const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
   BCG_TRY(halo_field(c, P));
+  if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/true));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
     note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
     ProfScope ps(c, "hop_ring", alg_bytes(c, m, 2, 1, n, L3));
@@ -661,18 +708,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   };
   const double c0 = mass * mass + sigma0;
   int total = 0;
-  BCG_TRY(first(L3 - 1, 1));
-  int next = 0;  // first slice of tmp not yet computed in order (L3 stands for slice 0 again)
-  for (int lo = 0; lo < L3; lo += C) {
-    const int hi = lo + C < L3 ? lo + C : L3;
-    const int last = hi < L3 ? hi : L3 - 1;
-    if (next <= last) BCG_TRY(first(next, last - next + 1));
-    if (hi == L3) {
-      BCG_TRY(halo_window(c, m, P->d, 0, 1, 0));  // its P faces were replaced by tmp faces of the first chunk
-      BCG_TRY(first(0, 1));
-    }
-    next = hi + 1;
-    BCG_TRY(halo_window(c, m, ring, lo, hi - lo, R));
+  auto second = [&](int lo, int hi) -> int {  // T[lo, hi) from tmp[lo - 1, hi]
     {
       ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring", alg_bytes(c, m, 3, 1, hi - lo, L3));
       const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
@@ -681,7 +717,44 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
       if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
       total += nb;
     }
-    BCG_TRY(check_launch(c, "hop_shifted_ring"));
+    return check_launch(c, "hop_shifted_ring");
+  };
+  BCG_TRY(first(L3 - 1, 1));
+  int next = 0;  // first slice of tmp not yet computed in order (L3 stands for slice 0 again)
+  // tmp up to one slice past chunk [lo, hi); at the end of the sweep slice L3 = slice 0 again, from the source's faces of
+  // slice 0: exchanged again (serial form) or put back from their copy (overlapped form: no second exchange in flight)
+  auto stage_first = [&](int lo) -> int {
+    const int hi = lo + C < L3 ? lo + C : L3;
+    const int last = hi < L3 ? hi : L3 - 1;
+    if (next <= last) BCG_TRY(first(next, last - next + 1));
+    if (hi == L3) {
+      if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/false));
+      else BCG_TRY(halo_window(c, m, P->d, 0, 1, 0));  // its P faces were replaced by tmp faces of the first chunk
+      BCG_TRY(first(0, 1));
+    }
+    next = hi + 1;
+    return BCG_OK;
+  };
+  if (!overlap) {
+    for (int lo = 0; lo < L3; lo += C) {
+      const int hi = lo + C < L3 ? lo + C : L3;
+      BCG_TRY(stage_first(lo));
+      BCG_TRY(halo_window(c, m, ring, lo, hi - lo, R));
+      BCG_TRY(second(lo, hi));
+    }
+  } else {
+    BCG_TRY(stage_first(0));
+    BCG_TRY(halo_window(c, m, ring, 0, (C < L3 ? C : L3), R, /*split=*/true));
+    for (int lo = 0; lo < L3; lo += C) {
+      const int hi = lo + C < L3 ? lo + C : L3;
+      if (hi < L3) BCG_TRY(stage_first(hi));  // chunk k + 1's slices of tmp, while chunk k's faces are on the links
+      {
+        ProfScope ps(c, "halo_exchange_end");
+        BCG_TRY(exchange_end(c));
+      }
+      if (hi < L3) BCG_TRY(halo_window(c, m, ring, hi, (hi + C < L3 ? C : L3 - hi), R, /*split=*/true));
+      BCG_TRY(second(lo, hi));  // ... and chunk k + 1's faces fly while chunk k's T is computed
+    }
   }
   if (gram) *gram_blocks = total;
   return BCG_OK;
@@ -689,19 +762,21 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
 
 // T = (mass^2 + sigma0) P - D(D(P))   [op + add(P, sigma0), inc/block_solvers.hpp:134-136]
 int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
-                  int* gram_blocks = nullptr) {
+                  int* gram_blocks = nullptr, bool* gram_folded = nullptr) {
+  if (gram_folded) *gram_folded = false;
   if (capacity_path(c, P->m)) return apply_shifted_ring(c, g, mass, sigma0, T, P, gram_blocks);
   bcg_field* tmp;
   BCG_TRY(get_tmp(c, P->m, &tmp));
   BCG_TRY(hop(c, g, tmp, P, bcg::HOP_PLAIN, nullptr, 0.0));
-  return hop(c, g, T, tmp, bcg::HOP_SHIFTED, P, mass * mass + sigma0, gram_blocks);
+  return hop(c, g, T, tmp, bcg::HOP_SHIFTED, P, mass * mass + sigma0, gram_blocks, gram_folded);
 }
 
 // Phase A of an iteration: T = (A + sigma0) P ; G = P^dagger T   (:134-140)
 int phase_A(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P, CMat& G) {
   int nb = 0;
-  BCG_TRY(apply_shifted(c, g, mass, sigma0, T, P, &nb));
-  if (nb > 0) return finish_gram(c, P->m, nb, G, true);
+  bool folded = false;
+  BCG_TRY(apply_shifted(c, g, mass, sigma0, T, P, &nb, &folded));
+  if (nb > 0) return finish_gram(c, P->m, nb, G, true, folded);
   return gram(c, P, T, G);
 }
 
@@ -719,10 +794,11 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
   int nb;
   {
     ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
-    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, c->row_blocks_B);
+    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, c->row_blocks_B,
+                            bcg::GramFold{c->dev_gram, c->fold_tickets});
   }
   BCG_TRY(check_launch(c, "phaseB"));
-  return finish_gram(c, m, nb, G2, true);
+  return finish_gram(c, m, nb, G2, true, /*folded=*/true);
 }
 
 // Phase C: Q <- Q rho^{-1} ; X_s += P_s A_s ; P_s <- P_s B_s + Q for the n active shifts
@@ -856,6 +932,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
+  if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
+  if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);
@@ -879,7 +957,7 @@ int bcg_context_destroy(bcg_context* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->tmp_field) {
-    (void)hipFree(kv.second->d);
+    (void)hipFree(kv.second->base);
     delete kv.second;
   }
   for (auto& kv : c->tmp_ring_buf)
@@ -888,11 +966,13 @@ int bcg_context_destroy(bcg_context* c) {
     if (kv.second.first) (void)hipFree(kv.second.first);
   if (c->halo_send) (void)hipFree(c->halo_send);
   if (c->halo_recv) (void)hipFree(c->halo_recv);
+  if (c->halo_save) (void)hipFree(c->halo_save);
   if (c->partials) (void)hipFree(c->partials);
   if (c->hop_tune.sync.counters) (void)hipFree(c->hop_tune.sync.counters);
   if (c->dev_mats) (void)hipFree(c->dev_mats);
   if (c->pin_mats) (void)hipHostFree(c->pin_mats);
   if (c->dev_gram) (void)hipFree(c->dev_gram);
+  if (c->fold_tickets) (void)hipFree(c->fold_tickets);
   if (c->pin_gram) (void)hipHostFree(c->pin_gram);
   if (c->staging) (void)hipFree(c->staging);
   for (auto& kv : c->prof)
@@ -1033,7 +1113,7 @@ int bcg_capacity_mode(bcg_context* c, int ring_slices) {
     c->tmp_ring_buf.clear();
     if (ring_slices != 0) {
       for (auto& kv : c->tmp_field) {
-        (void)hipFree(kv.second->d);
+        (void)hipFree(kv.second->base);
         delete kv.second;
       }
       c->tmp_field.clear();
@@ -1051,6 +1131,7 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
   total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
   total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
+  if (capacity_path(c, m)) total += static_cast<size_t>(c->ghost_sites) / c->lat.L[3] * 3 * m * sizeof(double2);  // saved slice-0 faces
   total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
   *bytes_out = total;
   return BCG_OK;
@@ -1061,13 +1142,19 @@ int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
   DeviceScope on_device(c);
   if (!c || !out) return BCG_ERR_INVALID;
   if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
-  bcg_field* f = new bcg_field{c, m, nullptr};
-  hipError_t e = hipMalloc(&f->d, field_bytes(c, m));
+  bcg_field* f = new bcg_field{c, m, nullptr, nullptr};
+  // Fields of the lattices that matter have power-of-two sizes (64^4 sites x 768 B = 12 GiB), allocated back to back, so the
+  // streaming kernels read the same offset of up to nine of them at once with identical low address bits.  A per-field
+  // stagger (a multiple of 256 B, so alignment is kept) spreads those accesses over the memory channels.
+  const size_t lead = c->field_stagger * static_cast<size_t>(c->fields_created % 16);
+  hipError_t e = hipMalloc(&f->base, field_bytes(c, m) + c->field_stagger * 16);
   if (e != hipSuccess) {
     delete f;
     c->err = std::string("bcg_field_create: hipMalloc: ") + hipGetErrorString(e);
     return BCG_ERR_HIP;
   }
+  f->d = reinterpret_cast<double2*>(static_cast<char*>(f->base) + lead);
+  c->fields_created += 1;
   *out = f;
   return BCG_OK;
 }
@@ -1076,7 +1163,7 @@ int bcg_field_destroy(bcg_field* f) {
   DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f) return BCG_OK;
   (void)hipStreamSynchronize(f->ctx->stream);
-  (void)hipFree(f->d);
+  (void)hipFree(f->base);
   delete f;
   return BCG_OK;
 }

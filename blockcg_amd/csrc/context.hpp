@@ -15,6 +15,7 @@ struct bcg_field {
   bcg_context* ctx;
   int m;
   double2* d;  // [V_local*3][m]
+  void* base;  // the allocation d points into (d = base + a stagger, see bcg_field_create)
 };
 
 struct bcg_gauge {
@@ -61,12 +62,18 @@ struct bcg_context {
   double2* halo_send = nullptr;
   double2* halo_recv = nullptr;
   size_t halo_bytes = 0;
+  void* halo_save = nullptr;             // capacity mode, overlapped exchanges: the source's received faces of slice x3 = 0
+  size_t halo_save_bytes = 0;
+  size_t field_stagger = 0;              // bytes: field k of a context starts (k mod 16) * stagger into its allocation (BCG_FIELD_STAGGER)
+  int fields_created = 0;
+  bool ring_overlap = true;              // capacity mode: overlap the per-chunk exchanges when the callbacks allow (BCG_RING_OVERLAP)
   double2* partials = nullptr;           // block partials of Gram products
   size_t partials_bytes = 0;
   double2* dev_mats = nullptr;           // ring of coefficient-matrix slots in device memory
   double* pin_mats = nullptr;            // pinned host mirror of the ring
   size_t mat_slot_bytes = 0;
   int mat_slots = 0, mat_next = 0, mat_in_flight = 0;
+  unsigned* fold_tickets = nullptr;      // 9 words: arrival counters of the in-kernel Gram fold (bcg::GramFold)
   double2* dev_gram = nullptr;           // reduced Gram matrix (device), all-reduced in place
   double* pin_gram = nullptr;            // pinned host copy
   double2* staging = nullptr;            // layout-conversion staging of bcg_field_download_sites

@@ -53,6 +53,21 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
 #define BCG_HOP4B_ROWDMA 0
 #endif
+#ifndef BCG_HOP4B_PREO     // tuning builds: with ROWDMA, the rows that leave the bundle one step ahead
+#define BCG_HOP4B_PREO 0
+#endif
+// tuning builds: what may be scheduled across the start of a direction's arithmetic in k_hop4b (0: nothing, the default;
+// 1: LDS reads -- the next direction's link reads may start under this direction's FMAs; 2: no scheduling barrier)
+#ifndef BCG_HOP4B_SCHED
+#define BCG_HOP4B_SCHED 0
+#endif
+#if BCG_HOP4B_SCHED == 0
+#define BCG_HOP4B_DIR_BARRIER __builtin_amdgcn_sched_barrier(0)
+#elif BCG_HOP4B_SCHED == 1
+#define BCG_HOP4B_DIR_BARRIER __builtin_amdgcn_sched_barrier(0x100)
+#else
+#define BCG_HOP4B_DIR_BARRIER
+#endif
 #ifndef BCG_HOP4B_STORE_SC1  // tuning builds: write-through output stores (the lines do not stay in the XCD's L2)
 #define BCG_HOP4B_STORE_SC1 0
 #endif
@@ -80,6 +95,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst));  // no "memory" clobber: it would force the callers' captured state into scratch;
 }                                            // the block barriers around every use order it against the compiler's LDS accesses
+// One row element per lane (16 bytes at sbase + voff + IMM) by a load hipcc does not see: its result counts as available at
+// once, so the CALLER waits (s_waitcnt vmcnt) before the first use.  For values loaded one loop iteration ahead: hipcc's
+// own bookkeeping loses count across the loop's back edge and waits for every load of the NEW iteration at their use.
+template <int IMM>
+__device__ __forceinline__ dv2 ld_sv_async(const char* sbase, unsigned voff) {
+  dv2 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
+  return r;
+}
 // link loads of the stencil (non-temporal loads were tried here: 13 % fewer L2 misses, no time gained)
 __device__ __forceinline__ dv2 ld_link(const dv2* p) { return *p; }
 __device__ __forceinline__ void st_nt(double2* p, double2 v) {
@@ -334,12 +358,78 @@ __device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, dou
   }
 }
 
+
+// ---- Gram partials folded inside the producing kernel ------------------------------------------------------------
+// After a block has written partials[blockIdx.x][NV], the LAST block to finish of each of 8 groups (blocks g, g + 8, ...)
+// sums its group's partials in block order into partials[gridDim.x + g], and the last of the 8 groups to finish sums those
+// in group order into `out`: a fixed order whatever the arrival order (bitwise reproducible), no separate reduction
+// launch.  The hand-off between workgroups follows the guide's recipe (every storing wave drains its stores, block
+// barrier, one lane: agent-scope release, ticket; the winner: agent-scope acquire, block barrier, plain loads).
+// tickets: 9 words, zero before the first launch; the final block leaves them zero again.  All threads of the block call it.
+template <int NV>
+__device__ __forceinline__ void gram_fold(const GramFold& gf, double2* __restrict__ partials, int tid, int nthreads) {
+  if (gf.out == nullptr) return;
+  __shared__ int s_role;
+  const int nb = gridDim.x, g = blockIdx.x & 7;
+  const int in_group = (nb - g + 7) >> 3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(gf.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_role = t == static_cast<unsigned>(in_group - 1) ? 1 : 0;
+    if (s_role) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!s_role) return;
+  double2* const level2 = partials + static_cast<int64_t>(nb) * NV;
+  for (int v = tid; v < NV; v += nthreads) {
+    double sr = 0.0, si = 0.0;
+    for (int b = g; b < nb; b += 8) {
+      const double2 t = partials[static_cast<int64_t>(b) * NV + v];
+      sr += t.x;
+      si += t.y;
+    }
+    level2[g * NV + v] = make_double2(sr, si);
+  }
+  const int groups = nb < 8 ? nb : 8;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(gf.tickets + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_role = t == static_cast<unsigned>(groups - 1) ? 2 : 0;
+    if (s_role) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (s_role != 2) return;
+  for (int v = tid; v < NV; v += nthreads) {
+    double sr = 0.0, si = 0.0;
+    for (int k = 0; k < groups; ++k) {
+      const double2 t = level2[k * NV + v];
+      sr += t.x;
+      si += t.y;
+    }
+    gf.out[v] = make_double2(sr, si);
+  }
+  if (tid < 9) gf.tickets[tid] = 0u;  // ready for the next launch (stream order makes this visible to it)
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Phase B:  Q -= T*alpha  (matrix passed as -alpha),  accumulate Q^dagger Q of the NEW Q.
 // ---------------------------------------------------------------------------------------------------
 template <int M>
 __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
-                                                const double2* __restrict__ negalpha, double2* __restrict__ partials) {
+                                                const double2* __restrict__ negalpha, double2* __restrict__ partials,
+                                                GramFold gf) {
   constexpr int NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row (M*16 + 16 bytes)
   constexpr int JB = M / 16;
@@ -359,7 +449,11 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
   const int64_t ntiles = (rows + 15) / 16;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
   int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
+#ifdef BCG_PHASEB_NO_AHEAD  // tuning build (tools/build_variant.sh): phase B without the next tile's loads in flight
+  constexpr bool AHEAD = false;
+#else
   constexpr bool AHEAD = M <= 16;
+#endif
   Tile<M> t, q;
   if (AHEAD && tile < ntiles) {
     tile_load<M>(t, T, tile * 16 + r, kq, tile * 16 + r < rows);
@@ -404,6 +498,7 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
     }
   }
   gram_block_store<M, NW>(G, scratch, partials, tid);
+  gram_fold<M * M>(gf, partials, tid, NW * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -706,6 +801,8 @@ struct HopWalk {
   // a few blocks (all x2-edge columns belong to two XCD classes), and that launch is on the critical path.
   const int* tile_list;
   int list_n;
+  // k_hop4c / k_hop4b with the fused Gram product: fold the block partials inside the kernel (gram_fold); out = nullptr: off
+  GramFold fold;
 };
 
 // Pacing counters are read with the same read-modify-write unit that increments them (an add of 0): the blocks of a
@@ -1437,6 +1534,7 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
   if (GRAM) {
     if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
     else gram_block_store<16, NW>(G, smem, partials, tid);
+    gram_fold<M * M>(hw.fold, partials, tid, NW * 64);
   }
 }
 
@@ -1511,6 +1609,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   constexpr int RBK = (SPW * 9 + 63) / 64;
   constexpr bool SHARE = hop4b_share_images(M);
   constexpr bool ROWDMA = BCG_HOP4B_ROWDMA != 0;  // +x3 row (own sites + halo sites) by LDS-DMA into its slot
+  // PREO (with ROWDMA): the two rows that leave the bundle are loaded ONE STEP AHEAD into registers, so that the first
+  // three directions of a step wait for nothing and the step's only fresh data -- the +x3 row -- has them to arrive in
+  constexpr bool PREO = ROWDMA && BCG_HOP4B_PREO != 0;
   constexpr int HB = 3 * M * 16;                  // bytes of one site = of one halo site
   constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site  // in-bundle backward links from the partner waves' images (2 images per wave)
   constexpr int RB = 3 * M * 16;           // bytes of one site of a field
@@ -1807,6 +1908,24 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         park_links(lo, true);
       }
     }
+    auto row_o = [&](bool k_o, int a_o, int s_o, int x3v, int slotv) __attribute__((always_inline)) {
+      return k_o ? ghb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(x3v) * s_o) * RB
+                 : inb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(RING_IN ? slotv : x3v) * s_o) * RB;
+    };
+    double2 o1[3], o2[3];
+    dv2 p1[3], p2[3];  // PREO: the rows of the NEXT step, loaded behind hipcc's back (ld_sv_async) and waited for by hand
+    if (PREO) {  // the first step's rows; every later step finds them loaded by the step before
+      const char* const q1 = row_o(k_o1, a_o1, s_o1, win.x3_lo, slot);
+      const char* const q2 = row_o(k_o2, a_o2, s_o2, win.x3_lo, slot);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q1, voff, c * M * 16);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q2, voff, c * M * 16);
+      // retire them HERE: a load still pending at the loop's entry makes hipcc wait for it at its use in EVERY iteration
+      // (it cannot tell the first from the rest), i.e. for everything the iteration itself has issued by then
+      asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y), "+v"(o1[1].x), "+v"(o1[1].y), "+v"(o1[2].x), "+v"(o1[2].y));
+      asm volatile("" : "+v"(o2[0].x), "+v"(o2[0].y), "+v"(o2[1].x), "+v"(o2[1].y), "+v"(o2[2].x), "+v"(o2[2].y));
+    }
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
       const int step_n = vs0 + x3;
       if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
@@ -1864,15 +1983,27 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           }
       }
       // ---- global loads of the step: the two rows that leave the bundle, the +x3 row with its halo, p
-      const char* const q_o1 = (k_o1 ? ghb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(x3) * s_o1) * RB
-                                     : inb + (static_cast<int64_t>(a_o1) + static_cast<int64_t>(RING_IN ? slot : x3) * s_o1) * RB);
-      const char* const q_o2 = (k_o2 ? ghb + (static_cast<int64_t>(a_o2) + static_cast<int64_t>(x3) * s_o2) * RB
-                                     : inb + (static_cast<int64_t>(a_o2) + static_cast<int64_t>(RING_IN ? slot : x3) * s_o2) * RB);
-      double2 o1[3], o2[3];
+      const bool more = x3 + 1 < x3_end;
+      const int slot_n = RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0;
+      if (PREO) {
+        if (more) {  // issued LAST among the step's loads and DMAs: nothing this step waits for is queued behind them
+          const char* const q1 = row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
+          const char* const q2 = row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
+          p1[0] = ld_sv_async<0>(q1, voff);
+          p1[1] = ld_sv_async<M * 16>(q1, voff);
+          p1[2] = ld_sv_async<2 * M * 16>(q1, voff);
+          p2[0] = ld_sv_async<0>(q2, voff);
+          p2[1] = ld_sv_async<M * 16>(q2, voff);
+          p2[2] = ld_sv_async<2 * M * 16>(q2, voff);
+        }
+      } else {
+        const char* const q_o1 = row_o(k_o1, a_o1, s_o1, x3, slot);
+        const char* const q_o2 = row_o(k_o2, a_o2, s_o2, x3, slot);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q_o1, voff, c * M * 16);
+        for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q_o1, voff, c * M * 16);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
+        for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
+      }
       dv2 hv[3];
       if (!ROWDMA) {
         int kind, xs, gx3;
@@ -1928,11 +2059,16 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
-        __builtin_amdgcn_sched_barrier(0);
+        BCG_HOP4B_DIR_BARRIER;
         if (ROWDMA && mu == 3) {
           // o1[0] is the oldest ordinary load of the step and younger than the row DMAs: once it is in its register the row
           // is in Cn; the clobber keeps the compiler from reading Cn earlier (or re-using bk[3], read from the same address)
-          asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y) : : "memory");
+          // (PREO: the oldest load issued BEHIND the row DMAs is the next step's o1n[0]; the last step of a column has none)
+          // PREO: behind the row DMAs come at most the six loads of the next step's rows (and, wherever hipcc put them, the
+          // three of p: then this waits for three more than it must) -- none in the last step of a column
+          if (!PREO) asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y) : : "memory");
+          else if (more) asm volatile("s_waitcnt vmcnt(6)" : : : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
           for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; f[3][c] = make_double2(v.x, v.y); }
         }
@@ -1984,6 +2120,11 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           if (halo_lane) Cn[ho + c * M] = hv[c];
         }
       }
+      if (PREO && more) {
+        // the next step's rows have had the whole step to arrive; no store of THIS step is queued yet, so vmcnt(0) waits
+        // for loads only (and for the previous step's stores, a step old).  The operands keep every use behind the wait.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p1[0]), "+v"(p1[1]), "+v"(p1[2]), "+v"(p2[0]), "+v"(p2[1]), "+v"(p2[2]));
+      }
       double2 tv[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -2007,6 +2148,13 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
       }
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
+      if (PREO && more) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          o1[c] = make_double2(p1[c].x, p1[c].y);
+          o2[c] = make_double2(p2[c].x, p2[c].y);
+        }
+      }
       BCG_STAMPB(7)   // tail: links/row parked, p, stores, pacing counters
     }
   }
@@ -2020,6 +2168,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   if (GRAM) {
     if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
     else gram_block_store<16, NW>(G, smem, partials, tid);
+    gram_fold<M * M>(hw.fold, partials, tid, NW * 64);
   }
 #undef BO_F
 #undef BO_SEL
@@ -2082,7 +2231,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma8(int64_t rows, const double2*
 
 // Phase B at m = 8: Q += T * negalpha through the m = 8 product tile, then the new 16 x 8 tile is re-read from a per-wave
 // LDS buffer in (row, column) ownership for the folded Gram product.
-__global__ void __launch_bounds__(256) k_phaseB8(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
+__global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
                                                  const double2* __restrict__ negalpha, double2* __restrict__ partials) {
   constexpr int M = 8, NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row
@@ -2118,6 +2267,7 @@ __global__ void __launch_bounds__(256) k_phaseB8(int64_t rows, double2* __restri
     }
   }
   gram_block_store_fold8<NW>(G, scratch, partials, tid);
+  gram_fold<64>(gf, partials, tid, NW * 64);
 }
 
 }  // namespace
@@ -2135,20 +2285,20 @@ int phaseC_max_shifts(int m, bool applies_rinv) {
 }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks) {
+                  double2* partials, int max_blocks, GramFold gf) {
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
   if (m == 8) {
     const size_t lds = sizeof(double) * (((MatLds<8>::DOUBLES + 1) & ~1) + 4 * 8 * 64);  // RED 2048 >= TRN 4*16*18
-    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials);
   } else if (m == 16) {
     constexpr int M = 16;
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf);
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * 66);  // TRN 4224 >= RED 2048: 50 KB, 3 blocks per CU
     allow_lds(k_phaseB<M>, lds);
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf);
   }
   return grid;
 }
@@ -2238,10 +2388,10 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
   pl.ntiles = static_cast<int>(lat.V / lat.L[3] * win.x3_n / SPB);
   const bool ok3 = walk == 3 && p0 > 0 && p1 > 0 && p2 > 0 && p0 % SPB == 0 && lat.L[0] % p0 == 0 && lat.L[1] % p1 == 0 &&
                    lat.L[2] % p2 == 0 && pl.ntiles % 8 == 0 && max_blocks % 8 == 0 && pl.ntiles / 8 >= max_blocks / 8;
-  pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, nullptr, 0};  // lexicographic = one patch
-  if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0, nullptr, 0};
+  pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, nullptr, 0, GramFold{}};  // lexicographic = one patch
+  if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0, nullptr, 0, GramFold{}};
   if (cls == 2 && tune.boundary_list != nullptr) {  // the boundary class from its tile list, round-robin
-    pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, tune.boundary_list, tune.boundary_n};
+    pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, tune.boundary_list, tune.boundary_n, GramFold{}};
     pl.grid = tune.boundary_n < max_blocks ? tune.boundary_n : max_blocks;
     pl.column = false;
     pl.list = true;
@@ -2286,7 +2436,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const HopPlan pl = plan_hop4(M, lat, max_blocks, tune, cls, win_in);
   if (!pl.valid) return -1;
   const int grid = pl.grid, ntiles = pl.ntiles;
-  const HopWalk hw = pl.hw;
+  HopWalk hw = pl.hw;
+  if (gram && pl.column && cls == 0) hw.fold = tune.fold;  // whole launches of the column forms fold their Gram partials
   const HopWindow win = pl.win;
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   if (pl.list && grid == 0) return 0;  // no boundary tiles
@@ -2383,6 +2534,13 @@ int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTunin
   const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
   const HopPlan pl = plan_hop4(m, lat, mb, tune, tile_class, win);
   return !pl.valid ? -1 : (pl.column ? 2 : 1);
+}
+
+bool hop_folds_gram(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, const HopWindow& win) {
+  if (!hop_can_split_tiles(m, lat) || (m != 16 && m != 8)) return false;
+  const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
+  const HopPlan pl = plan_hop4(m, lat, mb, tune, 0, win);
+  return pl.valid && pl.column;
 }
 
 bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,

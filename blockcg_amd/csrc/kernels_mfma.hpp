@@ -12,9 +12,17 @@ bool mfma_rows_width(int m);    // widths whose right-multiplications (phase C, 
 bool hop_fast_width(int m);     // widths served by the LDS-staged stencil kernel (8, 16, 32)
 int phaseC_max_shifts(int m, bool applies_rinv);  // shifts one phase-C launch can take (LDS budget; Rinv takes a slot)
 
+// Gram partials folded inside the producing kernel (kernels_mfma.hip: gram_fold): the last block to finish sums the block
+// partials in a fixed order into `out`, so no reduction launch follows.  out = nullptr: off.  The partials buffer needs
+// room for 8 more entries than blocks; tickets: 9 words, zero before the first use (the kernel leaves them zero).
+struct GramFold {
+  double2* out = nullptr;
+  unsigned* tickets = nullptr;
+};
+
 // Phase B: Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks);
+                  double2* partials, int max_blocks, GramFold fold = GramFold());
 // Phase C: if apply_rinv Q <- Q*mats[0]; for k < nshift: X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + Q.
 void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
                    const double2* mats, int apply_rinv, int max_blocks);
@@ -45,6 +53,7 @@ struct HopTuning {
   const int* boundary_list = nullptr;  // device list of the boundary tiles' first sites (set per launch by the context)
   int boundary_n = 0;
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
+  GramFold fold;                 // set per launch by the context: fold the fused Gram partials in the kernel (column forms)
   int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
                                  // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
                                  // so CUs are not vacated for the transport; its kernels co-reside where registers allow
@@ -68,6 +77,8 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
 bool hop_can_split_tiles(int m, const LatticeDev& lat);
 // Which kernel launch_hop_fast will use: 0 general (k_hop_fast), 1 k_hop4 (tile counter), 2 k_hop4c (column sweep), -1 rejected
 int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win);
+// true when a whole launch (tile class 0) with the fused Gram product folds its partials itself (HopTuning::fold honoured)
+bool hop_folds_gram(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, const HopWindow& win);
 // true when form 2 is served by k_hop4b (2 x 2 column bundles) rather than k_hop4c
 bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
                      bool plain = false);

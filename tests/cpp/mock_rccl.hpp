@@ -5,13 +5,16 @@
 //
 // Semantics kept from NCCL: point-to-point messages between a pair of ranks match in posting order (no tags); everything
 // inside ncclGroupStart/End is posted together (sends cannot block on the peer's receives); the all-reduce gives every rank
-// the same bits (contributions are added in rank order).  Transport: files under /dev/shm/<id>/ (host-staged), each call
-// synchronises the stream it was given first and completes before it returns, so later work on that stream sees the data.
+// the same bits (contributions are added in rank order); and every call is ASYNCHRONOUS and stream-ordered: it enqueues
+// copies and a host function on the stream it was given and returns at once (see "stream-ordered execution" below), so
+// that missing stream / event ordering in the caller shows up as stale data, as it would over RCCL.
+// Transport: files under /dev/shm/<id>/ (host-staged through pinned buffers).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -59,27 +62,104 @@ inline bool read_file(const std::string& path, void* data, size_t n, double time
     std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
 }
-inline ncclResult_t run(const std::vector<Op>& ops) {
-  std::vector<char> host;
-  for (const Op& o : ops)  // everything the streams were given before this call is done before any byte moves
-    if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclSystemError;
-  for (const Op& o : ops) {  // all sends first: a group never blocks on the peer's receives
-    if (!o.send) continue;
-    host.resize(o.bytes);
-    if (hipMemcpy(host.data(), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclSystemError;
-    const uint64_t seq = o.comm->sent[o.peer]++;
-    if (!write_file(o.comm->dir + "/p2p_" + std::to_string(o.comm->rank) + "_" + std::to_string(o.peer) + "_" + std::to_string(seq),
-                    host.data(), o.bytes))
-      return ncclSystemError;
+
+// ---- stream-ordered execution, like RCCL's ---------------------------------------------------------------------------
+// A call only ENQUEUES on the stream it was given and returns: device -> pinned copies of what is sent, a host function
+// (hipLaunchHostFunc: runs when the stream gets there, and holds the stream until it returns) that moves the bytes through
+// the files, pinned -> device copies of what was received.  So the begin/end choreography of the transport -- events
+// between the context's stream and the transfer stream, kernels queued behind an exchange that has not happened yet -- is
+// really exercised: work the caller failed to order behind the exchange runs BEFORE the data arrives and reads stale bytes.
+struct Piece { bool send; std::string path; void* host; size_t bytes; };
+struct Job {
+  mockComm* comm;
+  std::vector<Piece> pieces;                 // p2p: sends first, then receives
+  bool reduce = false;                       // all-reduce job: pieces[0] = own contribution (in/out, doubles)
+  std::string ar_base; int world = 1, rank = 0; ncclRedOp_t op = ncclSum; std::string ar_remove;
+};
+inline std::atomic<bool>& failed() { static std::atomic<bool> f{false}; return f; }
+struct Retired { hipEvent_t done; std::vector<void*> hosts; };
+inline std::vector<Retired>& retired() { static std::vector<Retired> r; return r; }
+inline void collect(bool all) {  // free pinned buffers whose stream work has finished
+  auto& r = retired();
+  for (size_t i = 0; i < r.size();) {
+    if (all) (void)hipEventSynchronize(r[i].done);
+    if (all || hipEventQuery(r[i].done) == hipSuccess) {
+      for (void* h : r[i].hosts) (void)hipHostFree(h);
+      (void)hipEventDestroy(r[i].done);
+      r.erase(r.begin() + i);
+    } else ++i;
   }
+}
+inline void host_fn(void* arg) {  // no HIP calls in here
+  Job* j = static_cast<Job*>(arg);
+  if (!j->reduce) {
+    for (const Piece& p : j->pieces)
+      if (p.send && !write_file(p.path, p.host, p.bytes)) failed() = true;
+    for (const Piece& p : j->pieces) {
+      if (p.send) continue;
+      if (!read_file(p.path, p.host, p.bytes)) { failed() = true; continue; }
+      std::remove(p.path.c_str());
+    }
+  } else {
+    const size_t count = j->pieces[0].bytes / 8;
+    double* mine = static_cast<double*>(j->pieces[0].host);
+    std::vector<double> other(count), acc(count);
+    if (!write_file(j->ar_base + std::to_string(j->rank), mine, count * 8)) failed() = true;
+    for (int r = 0; r < j->world; ++r) {  // rank order: identical bits on every rank
+      if (!read_file(j->ar_base + std::to_string(r), other.data(), count * 8)) { failed() = true; break; }
+      for (size_t i = 0; i < count; ++i)
+        acc[i] = r == 0 ? other[i] : (j->op == ncclMax ? (other[i] > acc[i] ? other[i] : acc[i]) : acc[i] + other[i]);
+    }
+    std::memcpy(mine, acc.data(), count * 8);
+    if (!j->ar_remove.empty()) std::remove(j->ar_remove.c_str());
+  }
+  delete j;
+}
+inline ncclResult_t finish(hipStream_t stream, std::vector<void*> hosts) {
+  Retired r;
+  if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, stream) != hipSuccess)
+    return ncclSystemError;
+  r.hosts = std::move(hosts);
+  retired().push_back(std::move(r));
+  return ncclSuccess;
+}
+inline ncclResult_t run(const std::vector<Op>& ops) {
+  if (failed()) return ncclSystemError;
+  collect(false);
+  // one job per stream, in posting order (the transport posts a group on one stream)
+  std::vector<hipStream_t> streams;
   for (const Op& o : ops) {
-    if (o.send) continue;
-    host.resize(o.bytes);
-    const uint64_t seq = o.comm->received[o.peer]++;
-    const std::string path = o.comm->dir + "/p2p_" + std::to_string(o.peer) + "_" + std::to_string(o.comm->rank) + "_" + std::to_string(seq);
-    if (!read_file(path, host.data(), o.bytes)) return ncclSystemError;
-    std::remove(path.c_str());
-    if (hipMemcpy(o.buf, host.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclSystemError;
+    bool seen = false;
+    for (hipStream_t s : streams) seen = seen || s == o.stream;
+    if (!seen) streams.push_back(o.stream);
+  }
+  for (hipStream_t s : streams) {
+    Job* j = new Job();
+    std::vector<void*> hosts;
+    std::vector<std::pair<void*, const Op*>> recvs;
+    for (int pass = 0; pass < 2; ++pass)
+      for (const Op& o : ops) {
+        if (o.stream != s || o.send != (pass == 0)) continue;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, o.bytes ? o.bytes : 1, hipHostMallocDefault) != hipSuccess) return ncclSystemError;
+        hosts.push_back(h);
+        j->comm = o.comm;
+        if (o.send) {
+          if (hipMemcpyAsync(h, o.buf, o.bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclSystemError;
+          const uint64_t seq = o.comm->sent[o.peer]++;
+          j->pieces.push_back(Piece{true, o.comm->dir + "/p2p_" + std::to_string(o.comm->rank) + "_" + std::to_string(o.peer) + "_" +
+                                              std::to_string(seq), h, o.bytes});
+        } else {
+          const uint64_t seq = o.comm->received[o.peer]++;
+          j->pieces.push_back(Piece{false, o.comm->dir + "/p2p_" + std::to_string(o.peer) + "_" + std::to_string(o.comm->rank) + "_" +
+                                               std::to_string(seq), h, o.bytes});
+          recvs.emplace_back(h, &o);
+        }
+      }
+    if (hipLaunchHostFunc(s, host_fn, j) != hipSuccess) return ncclSystemError;
+    for (auto& r : recvs)
+      if (hipMemcpyAsync(r.second->buf, r.first, r.second->bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclSystemError;
+    if (finish(s, std::move(hosts)) != ncclSuccess) return ncclSystemError;
   }
   return ncclSuccess;
 }
@@ -103,6 +183,7 @@ inline ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId i
   return ncclSuccess;
 }
 inline ncclResult_t ncclCommDestroy(ncclComm_t c) {
+  mock_rccl::collect(true);  // every enqueued transfer of this process has run
   if (c && c->rank == 0) {  // best effort: the directory is left for the other ranks to finish with and removed if empty
     rmdir(c->dir.c_str());
   }
@@ -132,18 +213,23 @@ inline ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer
 inline ncclResult_t ncclAllReduce(const void* in, void* out, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c,
                                   hipStream_t s) {
   if (t != ncclDouble) return ncclInvalidArgument;
-  if (hipStreamSynchronize(s) != hipSuccess) return ncclSystemError;
-  std::vector<double> mine(count), other(count), acc(count);
-  if (hipMemcpy(mine.data(), in, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclSystemError;
+  if (mock_rccl::failed()) return ncclSystemError;
+  mock_rccl::collect(false);
+  void* h = nullptr;
+  if (hipHostMalloc(&h, count * 8, hipHostMallocDefault) != hipSuccess) return ncclSystemError;
+  if (hipMemcpyAsync(h, in, count * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclSystemError;
   const uint64_t seq = c->collectives++;
-  const std::string base = c->dir + "/ar_" + std::to_string(seq) + "_";
-  if (!mock_rccl::write_file(base + std::to_string(c->rank), mine.data(), count * 8)) return ncclSystemError;
-  for (int r = 0; r < c->world; ++r) {  // rank order: identical bits on every rank
-    if (!mock_rccl::read_file(base + std::to_string(r), other.data(), count * 8)) return ncclSystemError;
-    for (size_t i = 0; i < count; ++i) acc[i] = r == 0 ? other[i] : (op == ncclMax ? (other[i] > acc[i] ? other[i] : acc[i]) : acc[i] + other[i]);
-  }
+  mock_rccl::Job* j = new mock_rccl::Job();
+  j->comm = c;
+  j->reduce = true;
+  j->pieces.push_back(mock_rccl::Piece{true, "", h, count * 8});
+  j->ar_base = c->dir + "/ar_" + std::to_string(seq) + "_";
+  j->world = c->world;
+  j->rank = c->rank;
+  j->op = op;
   // the files of collective seq are removed when everyone has surely read them: at collective seq + 2
-  if (seq >= 2) std::remove((c->dir + "/ar_" + std::to_string(seq - 2) + "_" + std::to_string(c->rank)).c_str());
-  if (hipMemcpy(out, acc.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclSystemError;
-  return ncclSuccess;
+  if (seq >= 2) j->ar_remove = c->dir + "/ar_" + std::to_string(seq - 2) + "_" + std::to_string(c->rank);
+  if (hipLaunchHostFunc(s, mock_rccl::host_fn, j) != hipSuccess) return ncclSystemError;
+  if (hipMemcpyAsync(out, h, count * 8, hipMemcpyHostToDevice, s) != hipSuccess) return ncclSystemError;
+  return mock_rccl::finish(s, std::vector<void*>{h});
 }

@@ -50,9 +50,15 @@ def main():
     B = bc.block_fermion_field(ctx, m).setRandom(seed=4)
     # operator alone
     out = bc.block_fermion_field(ctx, m)
+    ctx.profiling(True)
     D.op(out, B)
+    prof = ctx.profile()
+    ctx.profiling(False)
     if comm.error:
         raise comm.error
+    if os.environ.get("BCG_TEST_EXPECT_RING_OVERLAP") == "1":  # capacity mode took the overlapped form: split exchanges per chunk
+        assert prof.get("halo_exchange_begin", {}).get("count", 0) >= 2 and "hop_ring" in prof, prof
+        assert prof["halo_exchange_end"]["count"] == prof["halo_exchange_begin"]["count"], prof
     orc = oracle.Oracle()
     V = int(np.prod(gdims))
     U = orc.fill_gauge(gdims, 3)

@@ -42,7 +42,7 @@ def _sweep_mock_files():
         shutil.rmtree(d, ignore_errors=True)
 
 
-def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False):
+def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False, expect_ring_overlap=False):
     world = 1
     for g in grid:
         world *= g
@@ -51,6 +51,8 @@ def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overl
                BCG_HOP_BLOCKS=blocks, BCG_HOP_PATCH=patch, BCG_TEST_OVERLAP="1" if overlap else "0")
     if native:
         env.update(BCG_TEST_TRANSPORT="native", BCG_RCCL_LIB=_mock_transport())
+    if expect_ring_overlap:
+        env.update(BCG_TEST_EXPECT_RING_OVERLAP="1")
     port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
@@ -91,14 +93,35 @@ COLUMN_CASES = [
 def test_domain_decomposed_solve_column_sweep(dims, grid, m, ring, overlap):
     """overlap: the split exchange, i.e. the interior and the boundary tile classes of the column-sweep kernel in two
     launches (capacity mode never splits)."""
-    if overlap and ring:
-        pytest.skip("capacity mode does not use the split exchange")
-    _run_ranks(dims, grid, m, False, ring, blocks="32", patch="16,2,2", overlap=overlap)
+    # capacity mode with the split callbacks: the per-chunk exchanges of the ring overlap the stencil work (ring >= 4)
+    _run_ranks(dims, grid, m, False, ring, blocks="32", patch="16,2,2", overlap=overlap,
+               expect_ring_overlap=bool(overlap and ring >= 4))
 
 
 @pytest.mark.parametrize("dims,grid,m,ring", RING_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
 def test_domain_decomposed_solve_capacity_mode(dims, grid, m, ring):
-    _run_ranks(dims, grid, m, False, ring)
+    """gloo transport with the split callbacks: rings of >= 4 slices take the overlapped form (chunks of (ring - 2) / 2 slices,
+    exchange of chunk k posted while chunk k + 1's first stencil and chunk k - 1's second stencil run); ring 3 the serial one."""
+    _run_ranks(dims, grid, m, False, ring, expect_ring_overlap=ring >= 4)
+
+
+RING_OVERLAP_NATIVE = [
+    # dims,              grid,          m,  ring, blocks
+    ([64, 16, 8, 6], [2, 2, 1, 1], 16, 6, "32"),     # 4 ranks, two-slice chunks (3 of them), row form of the stencil
+    ([32, 16, 8, 24], [1, 2, 1, 1], 16, 24, "32"),   # ring = L3 = 24: chunks of 11, 11, 2 slices -> bundle sweep windows
+    ([32, 16, 8, 24], [1, 1, 2, 1], 16, 12, "32"),   # ring 12: five-slice chunks, last chunk short, the wrap slice restored from its copy
+    ([16, 4, 4, 12], [2, 1, 1, 1], 32, 4, "8"),      # m = 32, one-slice chunks
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,ring,blocks", RING_OVERLAP_NATIVE,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_capacity_mode_overlapped_exchanges_native_transport(dims, grid, m, ring, blocks):
+    """The headline's mode with its exchanges overlapped, over the NATIVE transport's split form (second stream + events):
+    per chunk pack -> halo_exchange_begin -> [first stencil of the next chunk] -> halo_exchange_end -> second stencil; the
+    source's faces of slice 0 are put back from a device copy for the wrap slice instead of a second exchange.  Each rank
+    checks operator, Gram matrix and solve against the whole-lattice oracle."""
+    _run_ranks(dims, grid, m, False, ring, blocks=blocks, patch="16,2,2", overlap=True, native=True, expect_ring_overlap=True)
 
 
 def test_rccl_on_library_memory_views():

@@ -99,19 +99,19 @@ def test_undivided_solve_with_native_comm_installed():
 
 
 def test_headline_share_fits_the_device():
-    """Rank 0 of the BASELINE headline (V = 128^4 on a (2,2,2,1) grid, m = 16, 4 shifts, capacity ring 16 as bench.py selects it, source consumed):
+    """Rank 0 of the BASELINE headline (V = 128^4 on a (2,2,2,1) grid, m = 16, 4 shifts, capacity ring 32 as bench.py selects it, source consumed):
     the library's own memory plan for one SBCGrQ solve stays under the 288 GiB of one MI355X with room for the runtime and
     RCCL's buffers; without the ring it does not."""
     import blockcg_amd as bc
     ctx = bc.Context([128] * 4, grid=[2, 2, 2, 1], coords=[0, 0, 0, 0])
     assert ctx.local_dims == [64, 64, 64, 128]
     whole = ctx.sbcgrq_device_bytes(16, 4, consume_B=True)
-    ctx.capacity_mode(16)
+    ctx.capacity_mode(32)
     ring = ctx.sbcgrq_device_bytes(16, 4, consume_B=True)
     hbm = 288 * 2**30
     assert ring < hbm - 16 * 2**30, ring / 2**30      # >= 16 GiB of headroom
     assert whole > hbm - 4 * 2**30, whole / 2**30     # the whole-field plan leaves (next to) nothing
-    assert whole - ring > 20e9
+    assert whole - ring > 19e9
 
 
 def test_interior_grid_cap_does_not_change_results(monkeypatch):
