@@ -46,7 +46,7 @@ def test_grid_and_plan_consistency():
 
 def test_bench_selects_the_headline_ladder():
     """bench.py --gpus N without shape flags: N = 1 is 64^4 (BASELINE configs[2]); N = 2, 4, 8 keep 64^3 x 128 sites per
-    GPU in capacity mode (ring 16) on grids (1,1,2,1), (1,2,2,1), (2,2,2,1), so that N = 8 is the headline 128^4."""
+    GPU in capacity mode (ring 32: two 15-slice chunks, exchanges overlapped) on grids (1,1,2,1), (1,2,2,1), (2,2,2,1), so that N = 8 is the headline 128^4."""
     import importlib.util
     import os
     from conftest import ROOT
@@ -58,7 +58,7 @@ def test_bench_selects_the_headline_ladder():
     want = {2: ([1, 1, 2, 1], [64, 64, 128, 128]), 4: ([1, 2, 2, 1], [64, 128, 128, 128]), 8: ([2, 2, 2, 1], [128] * 4)}
     for n, (grid, gdims) in want.items():
         local, cap, ladder = bench.resolve_shape(n, None, None)
-        assert (local, cap, ladder) == ([64, 64, 64, 128], 16, True)
+        assert (local, cap, ladder) == ([64, 64, 64, 128], 32, True)
         g = grid_for(n, 4, keep_last=cap > 0)
         assert g == grid and [l * x for l, x in zip(local, g)] == gdims
         assert sorted(tuple(coords_of(r, g)) for r in range(n)) == sorted(set(tuple(coords_of(r, g)) for r in range(n)))
