@@ -180,6 +180,11 @@ def main():
                     help="sites per GPU (default: 64 64 64 64 on one GPU, 64 64 64 128 on several)")
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--shifts", type=int, default=4)
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4],
+                    help="a BASELINE.json configuration by number: 2 = 64^4, m=16, 4 shifts on one GPU (the default at N=1); "
+                         "3 = the 128^4 ladder (the default at N>1); 4 = the wide-block stress, m=32 and 8 shifts, on the "
+                         "largest volume that fits: 64^3 x 32 sites per GPU (19 fields of 12.9 GB + links = 250 GB; the "
+                         "BASELINE's 128^4 would need 8 TB), i.e. 128^3 x 32 on 8 GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic VALU kernels")
     ap.add_argument("--capacity", type=int, default=None, metavar="R",
@@ -190,6 +195,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.config == 4:  # declared stand-in shape of configs[4] (see --config)
+        args.m, args.shifts = 32, 8
+        if args.local_dims is None:
+            args.local_dims = [64, 64, 64, 32]
+        if args.capacity is None:
+            args.capacity = 32 if world > 1 else 0  # ring = L3: no memory saved, but the chunked exchanges overlap
     if os.environ.get("BCG_BENCH_TEST_HANG"):  # tests/test_bench_launcher.py: a rank that never finishes
         time.sleep(3600)
     default_shape = args.local_dims is None and args.capacity is None
@@ -330,6 +341,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), "
                                    f"m={m}, {S} shifts, mass={MASS}, fixed-work (eps=0)"
+                                   + ("; BASELINE configs[4] (m=32, 8 shifts) on the largest volume that fits 288 GB per GPU"
+                                      if args.config == 4 else "")
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
                                       "(64^3x128 per GPU, capacity ring 32)" if default_shape else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},

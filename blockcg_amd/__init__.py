@@ -6,4 +6,4 @@ drop-in headers live in blockcg_amd/include/blockcg/.
 """
 from ._lib import build, load, LIB_PATH  # noqa: F401
 from .api import (BlockCGError, Context, block_fermion_field, dirac_op, SBCGrQ, SBCGrQState, SUPPORTED_WIDTHS, true_residuals,
-                  CG, SCG, BCG, BCGrQ)  # noqa: F401
+                  CG, SCG, BCG, BCGrQ, SBCGrQ_half_volume)  # noqa: F401

@@ -57,6 +57,11 @@ SIGNATURES = {
     "bcg_field_width": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_upload": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
     "bcg_field_download": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
+    "bcg_field_create_half": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "bcg_field_parity": (ctypes.c_int, [ctypes.c_void_p]),
+    "bcg_field_sites": (ctypes.c_int64, [ctypes.c_void_p]),
+    "bcg_field_parity_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "bcg_dirac_hop_half": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "bcg_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_download_sites": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), c_dbl_p]),

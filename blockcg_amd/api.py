@@ -122,12 +122,18 @@ class Context:
 class block_fermion_field:
     """Device block field (inc/fields.hpp:25-147).  `N_rhs` is the reference's template parameter."""
 
-    def __init__(self, ctx, N_rhs, host=None):
+    def __init__(self, ctx, N_rhs, host=None, parity=None):
+        """parity = 0 / 1: a half-volume field, the ctx.V / 2 sites of that parity (include/blockcg_hip.h,
+        bcg_field_create_half); every operation then takes operands of the same parity."""
         self.ctx = ctx
         self.N_rhs = int(N_rhs)
-        self.V = ctx.V
+        self.parity = parity
+        self.V = ctx.V if parity is None else ctx.V // 2
         h = ctypes.c_void_p()
-        ctx.check(ctx.lib.bcg_field_create(ctx.h, self.N_rhs, ctypes.byref(h)))
+        if parity is None:
+            ctx.check(ctx.lib.bcg_field_create(ctx.h, self.N_rhs, ctypes.byref(h)))
+        else:
+            ctx.check(ctx.lib.bcg_field_create_half(ctx.h, self.N_rhs, int(parity), ctypes.byref(h)))
         self.h = h
         if host is not None:
             self.upload(host)
@@ -139,6 +145,22 @@ class block_fermion_field:
             self.h = None
         except Exception:
             pass
+
+    # full field <-> its parity halves
+    def split_parity(self):
+        """(even, odd): new half-volume fields holding this field's sites of parity 0 and 1."""
+        out = []
+        for par in (0, 1):
+            half = block_fermion_field(self.ctx, self.N_rhs, parity=par)
+            self.ctx.check(self.ctx.lib.bcg_field_parity_copy(self.h, half.h, 1))
+            out.append(half)
+        return tuple(out)
+
+    def merge_parity(self, even, odd):
+        """This (full) field's sites of either parity <- the two half-volume fields."""
+        for half in (even, odd):
+            self.ctx.check(self.ctx.lib.bcg_field_parity_copy(self.h, half.h, 0))
+        return self
 
     # host <-> device
     def pinned_array(self):
@@ -274,8 +296,12 @@ class dirac_op:
         self.ctx.check(self.ctx.lib.bcg_dirac_apply(self.ctx.h, self.h, self.mass, lhs.h, rhs.h))
 
     def D(self, lhs, rhs):
-        """The reference's private hop (inc/dirac_op.hpp:14-21), exposed for tests."""
-        self.ctx.check(self.ctx.lib.bcg_dirac_hop(self.ctx.h, self.h, lhs.h, rhs.h))
+        """The reference's private hop (inc/dirac_op.hpp:14-21), exposed for tests.  Half-volume fields: lhs of the
+        parity opposite to rhs's."""
+        if getattr(rhs, "parity", None) is not None:
+            self.ctx.check(self.ctx.lib.bcg_dirac_hop_half(self.ctx.h, self.h, lhs.h, rhs.h))
+        else:
+            self.ctx.check(self.ctx.lib.bcg_dirac_hop(self.ctx.h, self.h, lhs.h, rhs.h))
 
 
 def SBCGrQ(X, B, D, sigma, eps=1.e-15, eps_shifts=1.e-15, max_iterations=1000000, trace_limit=0, consume_B=False,
@@ -357,6 +383,23 @@ def true_residuals(X, B, D, sigma):
     res = np.empty((S, B.N_rhs), dtype=np.float64)
     ctx.check(ctx.lib.bcg_true_residuals(ctx.h, D.h, D.mass, Xh, B.h, S, _dp(sig), _dp(res)))
     return res
+
+
+def SBCGrQ_half_volume(X, B, D, sigma, eps=1.e-15, eps_shifts=1.e-15, max_iterations=1000000):
+    """(op + sigma_s) X_s = B as two half-volume solves, one per site parity: dirac_op::D couples opposite parities only
+    (inc/dirac_op.hpp:14-21), so op = mass^2 - D^2 (inc/dirac_op.hpp:36-43) is block diagonal in the parity.  X, B: full
+    fields; each half solve runs inc/block_solvers.hpp:91-185 unchanged on half-volume fields (half the work fields'
+    memory).  Returns the operator applications of the (even, odd) solve.  A caller short of memory keeps half fields
+    only and calls SBCGrQ on them directly."""
+    its = []
+    halves = []
+    for par, Bp in enumerate(B.split_parity()):
+        Xp = [block_fermion_field(B.ctx, B.N_rhs, parity=par) for _ in X]
+        its.append(SBCGrQ(Xp, Bp, D, sigma, eps, eps_shifts, max_iterations, consume_B=True))
+        halves.append(Xp)
+    for s, x in enumerate(X):
+        x.merge_parity(halves[0][s], halves[1][s])
+    return tuple(its)
 
 
 def CG(x, b, D, eps=1.e-15, max_iterations=1000000):

@@ -270,7 +270,7 @@ int transfer_field(bcg_context* c, bcg_field* f, double* host, bool to_device) {
   BCG_TRY(ensure_xfer(c, !direct));
   BCG_TRY(stream_sync(c));  // order against everything enqueued on the context's stream
   const int64_t chunk = static_cast<int64_t>(c->xfer_bytes / site_bytes);
-  const int64_t V = c->lat.V;
+  const int64_t V = f->sites;
   const int64_t nchunks = (V + chunk - 1) / chunk;
   char* const hb = reinterpret_cast<char*>(host);
   auto sites_of = [&](int64_t i) { return std::min<int64_t>(chunk, V - i * chunk); };
@@ -305,7 +305,7 @@ int transfer_field(bcg_context* c, bcg_field* f, double* host, bool to_device) {
   return BCG_OK;
 }
 
-inline int64_t rows_of(const bcg_context* c) { return c->lat.V * 3; }
+inline int64_t rows_of(const bcg_field* f) { return f->sites * 3; }
 // algorithmic bytes: `fields` passes over a width-m field (s = 48 m bytes per site) plus `links` passes over the gauge
 // links (g = 144 ndim bytes per site), over the fraction num/den of the local volume
 inline double alg_bytes(const bcg_context* c, int m, double fields, double links = 0.0, int64_t num = 1, int64_t den = 1) {
@@ -313,6 +313,7 @@ inline double alg_bytes(const bcg_context* c, int m, double fields, double links
          static_cast<double>(den);
 }
 inline size_t field_bytes(const bcg_context* c, int m) { return static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2); }
+inline size_t field_bytes(const bcg_field* f) { return static_cast<size_t>(f->sites) * 3 * f->m * sizeof(double2); }
 
 // ---- halo exchange -----------------------------------------------------------------------------
 // rank = lexicographic index of grid coordinates, direction 0 fastest
@@ -462,7 +463,9 @@ int halo_gauge(bcg_context* c, bcg_gauge* g) {
 }
 
 // ---- building blocks ---------------------------------------------------------------------------
-bool same_shape(const bcg_field* a, const bcg_field* b) { return a && b && a->ctx == b->ctx && a->m == b->m; }
+bool same_shape(const bcg_field* a, const bcg_field* b) {
+  return a && b && a->ctx == b->ctx && a->m == b->m && a->parity == b->parity;
+}
 
 inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }       // + Gram, phase B
 inline bool fast_rmul(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_rows_width(m); }  // products, phase C
@@ -511,6 +514,7 @@ void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWind
 // path, HOP_SHIFTED) the kernel also leaves block partials of p^dagger out in c->partials.
 int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in, bcg::HopMode mode, const bcg_field* p,
         double c0, int* gram_blocks = nullptr, bool* gram_folded = nullptr) {
+  if (in->parity >= 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "D alone maps a half-volume field to the other parity: use bcg_dirac_hop_half");
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
   const int m = in->m;
   if (gram_blocks) *gram_blocks = 0;
@@ -609,8 +613,8 @@ int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool m
   int nblocks;
   {
     ProfScope ps(c, a == b ? "gram_self" : "gram_pair", alg_bytes(c, m, a == b ? 1 : 2));
-    if (fast_rows(c, m)) nblocks = bcg::launch_gram_mfma(c->stream, m, rows_of(c), a->d, b->d, c->partials, kFastBlocks);
-    else nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(c), a->d, b->d, c->partials, kMaxGramBlocks);
+    if (fast_rows(c, m)) nblocks = bcg::launch_gram_mfma(c->stream, m, rows_of(a), a->d, b->d, c->partials, kFastBlocks);
+    else nblocks = bcg::launch_gram_generic(c->stream, m, rows_of(a), a->d, b->d, c->partials, kMaxGramBlocks);
   }
   BCG_TRY(check_launch(c, "gram"));
   return finish_gram(c, m, nblocks, G, mirror);
@@ -621,8 +625,8 @@ int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double
   BCG_TRY(upload_mat(c, M, &Md));
   {
     ProfScope ps(c, name, alg_bytes(c, y->m, (x && x != y) ? 3 : 2));
-    if (fast_rmul(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
-    else bcg::launch_rmul_generic(c->stream, y->m, rows_of(c), y->d, x ? x->d : nullptr, Md, b, mode);
+    if (fast_rmul(c, y->m)) bcg::launch_rmul_mfma(c->stream, y->m, rows_of(y), y->d, x ? x->d : nullptr, Md, b, mode, kFastBlocks);
+    else bcg::launch_rmul_generic(c->stream, y->m, rows_of(y), y->d, x ? x->d : nullptr, Md, b, mode);
   }
   return check_launch(c, name);
 }
@@ -632,7 +636,7 @@ int trisolve(bcg_context* c, bcg_field* y, const CMat& R) {
   BCG_TRY(upload_mat(c, R, &Rd));
   {
     ProfScope ps(c, "trisolve", alg_bytes(c, y->m, 2));
-    bcg::launch_trisolve_generic(c->stream, y->m, rows_of(c), y->d, Rd);
+    bcg::launch_trisolve_generic(c->stream, y->m, rows_of(y), y->d, Rd);
   }
   return check_launch(c, "trisolve");
 }
@@ -640,7 +644,7 @@ int trisolve(bcg_context* c, bcg_field* y, const CMat& R) {
 int axpby(bcg_context* c, bcg_field* y, double a, const bcg_field* x, double b, const char* name) {
   {
     ProfScope ps(c, name);
-    bcg::launch_axpby(c->stream, y->d, a, x->d, b, rows_of(c) * y->m);
+    bcg::launch_axpby(c->stream, y->d, a, x->d, b, rows_of(y) * y->m);
   }
   return check_launch(c, name);
 }
@@ -654,6 +658,24 @@ int get_tmp(bcg_context* c, int m, bcg_field** out) {
   bcg_field* f = nullptr;
   BCG_TRY(bcg_field_create(c, m, &f));
   c->tmp_field[m] = f;
+  *out = f;
+  return BCG_OK;
+}
+// a new field of the width, parity and site count of `like`
+int create_like(bcg_context* c, const bcg_field* like, bcg_field** out) {
+  return like->parity >= 0 ? bcg_field_create_half(c, like->m, like->parity, out) : bcg_field_create(c, like->m, out);
+}
+// the half-volume `tmp` of parity `parity` (= D applied to a field of the other parity)
+int get_tmp_half(bcg_context* c, int m, int parity, bcg_field** out) {
+  const int key = m + 1000 * (1 + parity);
+  auto it = c->tmp_field.find(key);
+  if (it != c->tmp_field.end()) {
+    *out = it->second;
+    return BCG_OK;
+  }
+  bcg_field* f = nullptr;
+  BCG_TRY(bcg_field_create_half(c, m, parity, &f));
+  c->tmp_field[key] = f;
   *out = f;
   return BCG_OK;
 }
@@ -764,6 +786,22 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
 int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
                   int* gram_blocks = nullptr, bool* gram_folded = nullptr) {
   if (gram_folded) *gram_folded = false;
+  if (P->parity >= 0) {  // A restricted to one parity: tmp (other parity) = D P, T = (mass^2 + sigma0) P - D tmp
+    if (gram_blocks) *gram_blocks = 0;
+    if (T->parity != P->parity) BCG_FAIL(c, BCG_ERR_INVALID, "half-volume operator: result and argument must have the same parity");
+    bcg_field* tmp;
+    BCG_TRY(get_tmp_half(c, P->m, 1 - P->parity, &tmp));
+    {
+      ProfScope ps(c, "hop_half", alg_bytes(c, P->m, 2, 1, 1, 2));
+      bcg::launch_hop_half(c->stream, P->m, c->lat, tmp->parity, g->U, P->d, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
+    }
+    BCG_TRY(check_launch(c, "hop_half"));
+    {
+      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, P->m, 3, 1, 1, 2));
+      bcg::launch_hop_half(c->stream, P->m, c->lat, T->parity, g->U, tmp->d, T->d, bcg::HOP_SHIFTED, P->d, mass * mass + sigma0);
+    }
+    return check_launch(c, "hop_half_shifted");
+  }
   if (capacity_path(c, P->m)) return apply_shifted_ring(c, g, mass, sigma0, T, P, gram_blocks);
   bcg_field* tmp;
   BCG_TRY(get_tmp(c, P->m, &tmp));
@@ -794,7 +832,7 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
   int nb;
   {
     ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
-    nb = bcg::launch_phaseB(c->stream, m, rows_of(c), Q->d, T->d, Md, c->partials, c->row_blocks_B,
+    nb = bcg::launch_phaseB(c->stream, m, rows_of(Q), Q->d, T->d, Md, c->partials, c->row_blocks_B,
                             bcg::GramFold{c->dev_gram, c->fold_tickets});
   }
   BCG_TRY(check_launch(c, "phaseB"));
@@ -834,7 +872,7 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     {
       // the launch that applies rho^-1 reads and writes Q; a later launch of the same iteration (m = 32) re-reads it
       ProfScope ps(c, "phaseC", alg_bytes(c, m, (first ? 2 : 1) + 4 * ns));
-      bcg::launch_phaseC(c->stream, m, rows_of(c), Q->d, Xp, Pp, ns, Md, first, c->row_blocks_C);
+      bcg::launch_phaseC(c->stream, m, rows_of(Q), Q->d, Xp, Pp, ns, Md, first, c->row_blocks_C);
     }
     BCG_TRY(check_launch(c, "phaseC"));
   }
@@ -1138,16 +1176,21 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
 }
 
 // ---- fields ------------------------------------------------------------------------------------
-int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
-  DeviceScope on_device(c);
-  if (!c || !out) return BCG_ERR_INVALID;
+namespace {
+// parity -1: all local sites; 0 / 1: the parity-compact half (kernels_generic.hip, "Half-volume fields")
+int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
   if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
-  bcg_field* f = new bcg_field{c, m, nullptr, nullptr};
+  if (parity >= 0) {
+    if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
+    for (int mu = 0; mu < c->ndim; ++mu)
+      if (c->lat.L[mu] % 2 != 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: every lattice extent must be even");
+  }
+  bcg_field* f = new bcg_field{c, m, nullptr, nullptr, parity, parity >= 0 ? c->lat.V / 2 : c->lat.V};
   // Fields of the lattices that matter have power-of-two sizes (64^4 sites x 768 B = 12 GiB), allocated back to back, so the
   // streaming kernels read the same offset of up to nine of them at once with identical low address bits.  A per-field
   // stagger (a multiple of 256 B, so alignment is kept) spreads those accesses over the memory channels.
   const size_t lead = c->field_stagger * static_cast<size_t>(c->fields_created % 16);
-  hipError_t e = hipMalloc(&f->base, field_bytes(c, m) + c->field_stagger * 16);
+  hipError_t e = hipMalloc(&f->base, field_bytes(f) + c->field_stagger * 16);
   if (e != hipSuccess) {
     delete f;
     c->err = std::string("bcg_field_create: hipMalloc: ") + hipGetErrorString(e);
@@ -1157,6 +1200,28 @@ int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
   c->fields_created += 1;
   *out = f;
   return BCG_OK;
+}
+}  // namespace
+
+int bcg_field_create(bcg_context* c, int m, bcg_field** out) {
+  DeviceScope on_device(c);
+  if (!c || !out) return BCG_ERR_INVALID;
+  return create_field(c, m, -1, out);
+}
+int bcg_field_create_half(bcg_context* c, int m, int parity, bcg_field** out) {
+  DeviceScope on_device(c);
+  if (!c || !out || (parity != 0 && parity != 1)) return BCG_ERR_INVALID;
+  return create_field(c, m, parity, out);
+}
+int bcg_field_parity(const bcg_field* f) { return f ? f->parity : -2; }
+int64_t bcg_field_sites(const bcg_field* f) { return f ? f->sites : -1; }
+// half <- the sites of its parity of full, or the reverse
+int bcg_field_parity_copy(bcg_field* full, bcg_field* half, int to_half) {
+  DeviceScope on_device(full ? full->ctx : nullptr);
+  if (!full || !half || full->ctx != half->ctx || full->m != half->m || full->parity != -1 || half->parity < 0) return BCG_ERR_INVALID;
+  bcg_context* c = full->ctx;
+  bcg::launch_parity_copy(c->stream, full->m, c->lat, half->parity, full->d, half->d, to_half != 0);
+  return check_launch(c, "parity_copy");
 }
 
 int bcg_field_destroy(bcg_field* f) {
@@ -1194,7 +1259,7 @@ int bcg_field_download_sites(const bcg_field* f, int64_t n, const int64_t* sites
   if (!f || n < 0 || (n > 0 && (!sites || !host))) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   for (int64_t k = 0; k < n; ++k)
-    if (sites[k] < 0 || sites[k] >= c->lat.V) BCG_FAIL(c, BCG_ERR_INVALID, "bcg_field_download_sites: site out of range");
+    if (sites[k] < 0 || sites[k] >= f->sites) BCG_FAIL(c, BCG_ERR_INVALID, "bcg_field_download_sites: site out of range");
   const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
   const int64_t chunk = 4096;
   BCG_TRY(ensure_staging(c, static_cast<size_t>(chunk) * site_bytes));
@@ -1215,7 +1280,7 @@ int bcg_field_copy(bcg_field* dst, const bcg_field* src) {
   if (!same_shape(dst, src)) return BCG_ERR_INVALID;
   bcg_context* c = dst->ctx;
   ProfScope ps(c, "copy");
-  HIP_TRY(c, hipMemcpyAsync(dst->d, src->d, field_bytes(c, dst->m), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(dst->d, src->d, field_bytes(dst), hipMemcpyDeviceToDevice, c->stream));
   return BCG_OK;
 }
 
@@ -1224,7 +1289,7 @@ int bcg_field_set_zero(bcg_field* f) {
   if (!f) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
   ProfScope ps(c, "set_zero");
-  HIP_TRY(c, hipMemsetAsync(f->d, 0, field_bytes(c, f->m), c->stream));
+  HIP_TRY(c, hipMemsetAsync(f->d, 0, field_bytes(f), c->stream));
   return BCG_OK;
 }
 
@@ -1232,7 +1297,8 @@ int bcg_field_fill_random(bcg_field* f, uint64_t seed) {
   DeviceScope on_device(f ? f->ctx : nullptr);
   if (!f) return BCG_ERR_INVALID;
   bcg_context* c = f->ctx;
-  bcg::launch_fill_field(c->stream, f->m, c->lat, c->gdims, f->d, seed);
+  if (f->parity >= 0) bcg::launch_fill_field_half(c->stream, f->m, c->lat, c->gdims, f->parity, f->d, seed);
+  else bcg::launch_fill_field(c->stream, f->m, c->lat, c->gdims, f->d, seed);
   return check_launch(c, "fill_field");
 }
 
@@ -1358,6 +1424,16 @@ int bcg_dirac_hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_
   return hop(c, g, out, in, bcg::HOP_PLAIN, nullptr, 0.0);
 }
 
+// out (parity p) = D in (parity 1 - p): the two off-diagonal blocks of D in the parity basis
+int bcg_dirac_hop_half(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in) {
+  DeviceScope on_device(c);
+  if (!c || !g || !out || !in || out == in || g->ctx != c || in->ctx != c || out->ctx != c || out->m != in->m || in->parity < 0 ||
+      out->parity != 1 - in->parity)
+    return BCG_ERR_INVALID;
+  bcg::launch_hop_half(c->stream, in->m, c->lat, out->parity, g->U, in->d, out->d, bcg::HOP_PLAIN, nullptr, 0.0);
+  return check_launch(c, "hop_half");
+}
+
 int bcg_dirac_apply(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* out, const bcg_field* in) {
   DeviceScope on_device(c);
   if (!c || !g || !same_shape(out, in) || out == in || g->ctx != c || in->ctx != c) return BCG_ERR_INVALID;
@@ -1380,13 +1456,16 @@ int real_dot(bcg_context* c, const bcg_field* a, const bcg_field* b, double& out
 struct FieldPool {  // work fields of one solver call, released together
   bcg_context* c;
   std::vector<bcg_field*> f;
+  int parity = -1;  // of the fields made without an `init` to copy: set it to the parity of the solve's source
   explicit FieldPool(bcg_context* ctx) : c(ctx) {}
   ~FieldPool() {
     for (bcg_field* p : f) bcg_field_destroy(p);
   }
   int make(int m, bcg_field** out, const bcg_field* init = nullptr) {
     bcg_field* p = nullptr;
-    BCG_TRY(bcg_field_create(c, m, &p));
+    const int par = init ? init->parity : parity;
+    if (par >= 0) BCG_TRY(bcg_field_create_half(c, m, par, &p));
+    else BCG_TRY(bcg_field_create(c, m, &p));
     f.push_back(p);
     if (init) BCG_TRY(bcg_field_copy(p, init));
     *out = p;
@@ -1407,6 +1486,7 @@ int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_fiel
   if (!c || !g || !X || !B || !sigma || !res_out || n_shifts < 1 || g->ctx != c || B->ctx != c) return BCG_ERR_INVALID;
   const int m = B->m;
   FieldPool pool(c);
+  pool.parity = B->parity;
   bcg_field* AX = nullptr;  // only the unfused path needs it
   CMat b2, r2;
   BCG_TRY(gram(c, B, B, b2));
@@ -1415,7 +1495,7 @@ int bcg_true_residuals(bcg_context* c, const bcg_gauge* g, double mass, bcg_fiel
     // One pass where the bundle stencil applies (m = 16, whole-field tmp): tmp = D X_s, then the second stencil
     // forms (mass^2 + sigma_s) X_s - D tmp - B in registers and accumulates its Gram product; AX is never written
     // (5 field passes + 2 link passes instead of 9 + 2).
-    if (m == 16 && fast_hop(c, m) && !capacity_path(c, m) &&
+    if (m == 16 && B->parity < 0 && fast_hop(c, m) && !capacity_path(c, m) &&
         bcg::hop_uses_bundle(m, c->lat, kFastBlocks, c->hop_tune, 0, bcg::HopWindow())) {
       bcg_field* tmp;
       BCG_TRY(get_tmp(c, m, &tmp));
@@ -1453,6 +1533,7 @@ int bcg_cg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* x, 
   FieldPool pool(c);
   bcg_field *t, *p, *r;
   BCG_TRY(bcg_field_set_zero(x));  // :5
+  pool.parity = b->parity;
   BCG_TRY(pool.make(1, &t));
   BCG_TRY(pool.make(1, &p, b));    // :7
   BCG_TRY(pool.make(1, &r, b));    // :8
@@ -1497,6 +1578,7 @@ int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* co
     BCG_TRY(pool.make(1, &p[s], b));           // :53
   }
   bcg_field *t, *r;
+  pool.parity = b->parity;
   BCG_TRY(pool.make(1, &t));
   BCG_TRY(pool.make(1, &r, b));                // :54
   double rr, pt;
@@ -1531,7 +1613,7 @@ int bcg_scg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* co
     for (int s = 0; s < active; ++s) { xs[s] = x[s]->d; ps[s] = p[s]->d; }
     {
       ProfScope ps_(c, "scg_update");
-      bcg::launch_scg_update(c->stream, r->d, active, xs.data(), ps.data(), a_s.data(), b_s.data(), z_s.data(), rows_of(c));
+      bcg::launch_scg_update(c->stream, r->d, active, xs.data(), ps.data(), a_s.data(), b_s.data(), z_s.data(), rows_of(r));
     }
     BCG_TRY(check_launch(c, "scg_update"));
     if (std::sqrt(rr) * zeta[active - 1] < eps_shifts) --active;           // :90-92
@@ -1550,6 +1632,7 @@ int bcg_bcg_solve(bcg_context* c, const bcg_gauge* g, double mass, bcg_field* X,
   FieldPool pool(c);
   bcg_field *T, *P, *R;
   BCG_TRY(bcg_field_set_zero(X));   // :14
+  pool.parity = B->parity;
   BCG_TRY(pool.make(m, &T));
   BCG_TRY(pool.make(m, &P, B));     // :16
   BCG_TRY(pool.make(m, &R, B));
@@ -1745,18 +1828,18 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
     }                            \
   } while (0)
   // T, Q (:109).  T is overwritten before it is read, so it is not initialised from B.
-  BEGIN_TRY(bcg_field_create(c, m, &st->T));
+  BEGIN_TRY(create_like(c, B, &st->T));
   if (consume_B) {
     st->Q = B;
   } else {
-    BEGIN_TRY(bcg_field_create(c, m, &st->Q));
+    BEGIN_TRY(create_like(c, B, &st->Q));
     BEGIN_TRY(bcg_field_copy(st->Q, B));
   }
   for (int s = 0; s < n_shifts; ++s) BEGIN_TRY(bcg_field_set_zero(X[s]));  // :111-113
   BEGIN_TRY(thin_qr(c, st->Q, st->delta));                                  // :115
   st->rho = st->delta;                                                      // :116
   for (int s = 0; s < n_shifts; ++s) {                                      // :117
-    BEGIN_TRY(bcg_field_create(c, m, &st->P[s]));
+    BEGIN_TRY(create_like(c, B, &st->P[s]));
     BEGIN_TRY(bcg_field_copy(st->P[s], st->Q));
   }
 #undef BEGIN_TRY

@@ -16,6 +16,8 @@ struct bcg_field {
   int m;
   double2* d;  // [V_local*3][m]
   void* base;  // the allocation d points into (d = base + a stagger, see bcg_field_create)
+  int parity = -1;       // -1: all sites of the local lattice; 0 / 1: the sites of that parity only (bcg_field_create_half)
+  int64_t sites = 0;     // sites it holds: V_local, or V_local / 2
 };
 
 struct bcg_gauge {
@@ -55,7 +57,8 @@ struct bcg_context {
   bcg::HopTuning hop_tune;  // specialised stencil: tile walk, patch shape, grid, streaming hints
 
   // scratch
-  std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39)
+  std::map<int, bcg_field*> tmp_field;   // per width: the `tmp` of dirac_op::op (inc/dirac_op.hpp:39); key m + 1000 (1 + parity)
+                                         // for the half-volume ones
   int tmp_ring = 0;                      // capacity mode: `tmp` kept as a ring of this many x3 slices (0 = whole field)
   std::map<int, double2*> tmp_ring_buf;  // per width: the ring, tmp_ring * stride[3] * 3m complex
   std::map<int, std::pair<int*, int>> boundary_tiles;  // per tile length: device list of the boundary tiles' first sites

@@ -322,6 +322,120 @@ __global__ void __launch_bounds__(256) k_hop_generic(LatticeDev lat, const doubl
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Half-volume (parity-compact) fields.  D couples sites of opposite parity only (inc/dirac_op.hpp:14-21: nearest
+// neighbours), so A = mass^2 - D^2 is block diagonal in the parity x_0 + x_1 + x_2 + x_3 (mod 2) and the solve splits into
+// two half-volume solves.  A field of parity p holds the V/2 sites of that parity: half site
+// h = k + (L0/2) * (x1 + L1 * (x2 + L2 * x3)) is the full-lattice site with x0 = 2 k + ((x1 + x2 + x3 + p + o) & 1), o the
+// parity of the local origin.  All extents even.  Links keep the full-lattice layout.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void half_coords(const LatticeDev& lat, int64_t h, int parity, int x[4]) {
+  const int h0 = lat.L[0] >> 1;
+  const int k = static_cast<int>(h % h0); h /= h0;
+  x[1] = static_cast<int>(h % lat.L[1]); h /= lat.L[1];
+  x[2] = static_cast<int>(h % lat.L[2]); h /= lat.L[2];
+  x[3] = static_cast<int>(h);
+  const int o = lat.origin[0] + lat.origin[1] + lat.origin[2] + lat.origin[3];
+  x[0] = 2 * k + ((x[1] + x[2] + x[3] + parity + o) & 1);
+}
+__device__ __forceinline__ int64_t half_index(const LatticeDev& lat, const int x[4]) {
+  return (x[0] >> 1) + static_cast<int64_t>(lat.L[0] >> 1) * (x[1] + static_cast<int64_t>(lat.L[1]) * (x[2] + static_cast<int64_t>(lat.L[2]) * x[3]));
+}
+__device__ __forceinline__ int64_t full_index(const LatticeDev& lat, const int x[4]) {
+  return x[0] + static_cast<int64_t>(lat.L[0]) * (x[1] + static_cast<int64_t>(lat.L[1]) * (x[2] + static_cast<int64_t>(lat.L[2]) * x[3]));
+}
+
+// out (parity p) = D in (parity 1 - p)   [HOP_PLAIN]   or   out = c0 * pfield - D in   [HOP_SHIFTED; pfield of parity p].
+// The arithmetic per site is k_hop_generic's, term for term (same results as the full-volume operator on that site).
+// Undivided lattices only (no ghost faces).
+template <int M, int MODE>
+__global__ void __launch_bounds__(256) k_hop_half(LatticeDev lat, int parity, const double2* __restrict__ U,
+                                                  const double2* __restrict__ in, double2* __restrict__ out,
+                                                  const double2* __restrict__ p, double c0) {
+  constexpr int SPB = 256 / M;
+  const int sl = threadIdx.x / M;
+  const int j = threadIdx.x - sl * M;
+  const int64_t h = static_cast<int64_t>(blockIdx.x) * SPB + sl;
+  if (sl >= SPB || h >= lat.V / 2) return;
+  int x[4];
+  half_coords(lat, h, parity, x);
+  const int64_t site = full_index(lat, x);
+  double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+  int par = 0;  // x_0 + ... + x_{mu-1} (global)
+  for (int mu = 0; mu < lat.ndim; ++mu) {
+    const double eta = (par & 1) ? -1.0 : 1.0;
+    int xf[4] = {x[0], x[1], x[2], x[3]}, xb[4] = {x[0], x[1], x[2], x[3]};
+    xf[mu] = x[mu] + 1 < lat.L[mu] ? x[mu] + 1 : 0;
+    xb[mu] = x[mu] > 0 ? x[mu] - 1 : lat.L[mu] - 1;
+    const double2* pf = in + half_index(lat, xf) * 3 * M;
+    const double2* pb = in + half_index(lat, xb) * 3 * M;
+    const double2* ub = U + (full_index(lat, xb) * lat.ndim + mu) * 9;
+    const double2* uf = U + (site * lat.ndim + mu) * 9;
+    double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double2 psf = pf[k * M + j];
+      const double2 psb = pb[k * M + j];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        cfma(t[r], uf[k * 3 + r], psf);
+        const double2 v = ub[r * 3 + k];
+        t[r].x = fma(-v.x, psb.x, t[r].x); t[r].x = fma(-v.y, psb.y, t[r].x);
+        t[r].y = fma(-v.x, psb.y, t[r].y); t[r].y = fma(v.y, psb.x, t[r].y);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      acc[r].x = fma(eta, t[r].x, acc[r].x);
+      acc[r].y = fma(eta, t[r].y, acc[r].y);
+    }
+    par += x[mu] + lat.origin[mu];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int64_t o = (h * 3 + r) * M + j;
+    if (MODE == HOP_PLAIN) {
+      out[o] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+    } else {
+      const double2 pv = p[o];
+      out[o] = make_double2(fma(c0, pv.x, -0.5 * acc[r].x), fma(c0, pv.y, -0.5 * acc[r].y));
+    }
+  }
+}
+
+// full field <-> its two parity-compact halves (to_half: half = full restricted; else: full sites of that parity = half)
+__global__ void k_parity_copy(int m, LatticeDev lat, int parity, double2* __restrict__ full, double2* __restrict__ half, int to_half) {
+  const int row = 3 * m;
+  const int64_t n = lat.V / 2 * row;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t h = i / row;
+    const int e = static_cast<int>(i - h * row);
+    int x[4];
+    half_coords(lat, h, parity, x);
+    const int64_t fi = full_index(lat, x) * row + e;
+    if (to_half) half[i] = full[fi];
+    else full[fi] = half[i];
+  }
+}
+// the counter-based generator on a half field: the values the full field has at those sites
+__global__ void k_fill_field_half(int m, LatticeDev lat, GDims g, int parity, double2* __restrict__ f, uint64_t seed_mixed) {
+  const int row = 3 * m;
+  const int64_t n = lat.V / 2 * row;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t h = i / row;
+    const int e = static_cast<int>(i - h * row);
+    const int c = e / m, j = e - c * m;
+    int x[4];
+    half_coords(lat, h, parity, x);
+    const uint64_t gx = static_cast<uint64_t>(global_site(lat, g.d, full_index(lat, x)));
+    const uint64_t cnt = ((gx * m + j) * 3 + c) * 2;
+    f[i] = make_double2(uniform_pm1(seed_mixed, cnt), uniform_pm1(seed_mixed, cnt + 1));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K5 / K6: right-multiplication of every row by an m x m matrix.  Thread (row, j) computes one
 // output element; the input rows of the tile and the matrix (stored transposed so lanes j read
@@ -598,6 +712,27 @@ void launch_hop_generic(hipStream_t s, int m, const LatticeDev& lat, const doubl
       hipLaunchKernelGGL((k_hop_generic<M, HOP_SHIFTED>), dim3(grid), dim3(SPB * M), 0, s, lat, U, Ughost, in, ghost,
                          out, p, c0);
   });
+}
+
+void launch_hop_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* U, const double2* in, double2* out,
+                     HopMode mode, const double2* p, double c0) {
+  BCG_DISPATCH_M(m, {
+    constexpr int SPB = 256 / M;
+    const unsigned grid = static_cast<unsigned>((lat.V / 2 + SPB - 1) / SPB);
+    if (mode == HOP_PLAIN)
+      hipLaunchKernelGGL((k_hop_half<M, HOP_PLAIN>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, in, out, p, c0);
+    else
+      hipLaunchKernelGGL((k_hop_half<M, HOP_SHIFTED>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, in, out, p, c0);
+  });
+}
+void launch_parity_copy(hipStream_t s, int m, const LatticeDev& lat, int parity, double2* full, double2* half, bool to_half) {
+  hipLaunchKernelGGL(k_parity_copy, dim3(grid_for(lat.V / 2 * 3 * m, 256, 8192)), dim3(256), 0, s, m, lat, parity, full, half,
+                     to_half ? 1 : 0);
+}
+void launch_fill_field_half(hipStream_t s, int m, const LatticeDev& lat, const int* gdims, int parity, double2* f, uint64_t seed) {
+  GDims g{{gdims[0], gdims[1], gdims[2], gdims[3]}};
+  hipLaunchKernelGGL(k_fill_field_half, dim3(grid_for(lat.V / 2 * 3 * m, 256, 8192)), dim3(256), 0, s, m, lat, g, parity, f,
+                     splitmix64_host(seed));
 }
 
 void launch_rmul_generic(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Md, double b,

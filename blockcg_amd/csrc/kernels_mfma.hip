@@ -449,10 +449,13 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
   const int64_t ntiles = (rows + 15) / 16;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
   int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
-#ifdef BCG_PHASEB_NO_AHEAD  // tuning build (tools/build_variant.sh): phase B without the next tile's loads in flight
-  constexpr bool AHEAD = false;
-#else
+  // AHEAD: the next tile's loads in flight while this one is multiplied (m <= 16; BCG_PHASEB_AHEAD tuning build).  Off:
+  // measured over repeated bench runs on one device (tools/ab_bench.sh, profiles/r03_phaseB_ab.txt) the kernel with it
+  // took 7.3 ms in some processes and 8.1 ms in others, without it 7.16-7.25 ms in all of them.
+#ifdef BCG_PHASEB_AHEAD
   constexpr bool AHEAD = M <= 16;
+#else
+  constexpr bool AHEAD = false;
 #endif
   Tile<M> t, q;
   if (AHEAD && tile < ntiles) {

@@ -6,6 +6,7 @@
 #ifndef BLOCKCG_BLOCK_SOLVERS_HPP
 #define BLOCKCG_BLOCK_SOLVERS_HPP
 #include <algorithm>
+#include <utility>
 
 #include "dirac_op.hpp"
 #include "fields.hpp"
@@ -44,6 +45,26 @@ int SBCGrQ_consuming_source(std::vector<block_fermion_field<N_rhs>>& X, block_fe
   for (auto& x : X) x.device_written();
   B.device_written();
   return iterations;
+}
+// Half-volume (parity-decoupled) solve, SURVEY.md section 8f-4: dirac_op::D couples opposite site parities only
+// (inc/dirac_op.hpp:14-21), so op + sigma is block diagonal in the parity and the solve splits into two on V / 2 sites,
+// each the reference's SBCGrQ unchanged on half fields (half the work fields' memory).  X, B: full fields of a 4-D lattice
+// with even extents on one GPU.  Returns the operator applications of the even and of the odd solve.
+template <int N_rhs>
+std::pair<int, int> SBCGrQ_half_volume(std::vector<block_fermion_field<N_rhs>>& X, const block_fermion_field<N_rhs>& B,
+                                       const dirac_op& D, std::vector<double>& sigma, double eps = 1.e-15,
+                                       double eps_shifts = 1.e-15, int max_iterations = 1e6) {
+  int its[2] = {0, 0};
+  for (int par = 0; par < 2; ++par) {
+    block_fermion_field<N_rhs> Bp(D.lat(), par);
+    Bp.restrict_from(B);
+    std::vector<block_fermion_field<N_rhs>> Xp;
+    Xp.reserve(X.size());
+    for (size_t s = 0; s < X.size(); ++s) Xp.emplace_back(D.lat(), par);
+    its[par] = SBCGrQ_consuming_source(Xp, Bp, D, sigma, eps, eps_shifts, max_iterations);
+    for (size_t s = 0; s < X.size(); ++s) X[s].insert(Xp[s]);
+  }
+  return std::make_pair(its[0], its[1]);
 }
 }  // namespace blockcg
 

@@ -124,7 +124,23 @@ class block_fermion_field {
 
   explicit block_fermion_field(int V_) : V(V_), lat_(&blockcg::lattice::one_dimensional(V_)) { alloc(); }  // :35
   explicit block_fermion_field(blockcg::lattice& lat) : V(lat.V()), lat_(&lat) { alloc(); }
-  block_fermion_field(const block_fermion_field& o) : V(o.V), lat_(o.lat_) {  // deep copy, value semantics
+  // Half-volume field: the lat.V() / 2 sites of one parity (include/blockcg_hip.h, bcg_field_create_half).  dirac_op::op,
+  // every member below and every solver take operands of one parity; see blockcg::SBCGrQ_half_volume.
+  block_fermion_field(blockcg::lattice& lat, int parity) : V(lat.V() / 2), lat_(&lat), parity_(parity) { alloc(); }
+  int parity() const { return parity_; }  // -1: all sites
+  // this (half) <- the sites of its parity of `full`
+  void restrict_from(const block_fermion_field& full) {
+    full.flush();
+    blockcg::check(bcg_field_parity_copy(full.f_, f_, 1), lat_->ctx(), "bcg_field_parity_copy");
+    host_valid_ = host_dirty_ = false;
+  }
+  // this (full): its sites of half's parity <- half
+  void insert(const block_fermion_field& half) {
+    dev1();
+    half.flush();
+    blockcg::check(bcg_field_parity_copy(f_, half.f_, 0), lat_->ctx(), "bcg_field_parity_copy");
+  }
+  block_fermion_field(const block_fermion_field& o) : V(o.V), lat_(o.lat_), parity_(o.parity_) {  // deep copy, value semantics
     alloc();
     o.flush();
     blockcg::rand_state_guard keep_callers_rand_sequence;
@@ -265,7 +281,8 @@ class block_fermion_field {
  private:
   void alloc() {
     blockcg::rand_state_guard keep_callers_rand_sequence;
-    blockcg::check(bcg_field_create(lat_->ctx(), N_rhs, &f_), lat_->ctx(), "bcg_field_create");
+    if (parity_ >= 0) blockcg::check(bcg_field_create_half(lat_->ctx(), N_rhs, parity_, &f_), lat_->ctx(), "bcg_field_create_half");
+    else blockcg::check(bcg_field_create(lat_->ctx(), N_rhs, &f_), lat_->ctx(), "bcg_field_create");
   }
   void pull() const {
     if (!host_valid_) {
@@ -283,6 +300,7 @@ class block_fermion_field {
     rhs.flush();
   }
   blockcg::lattice* lat_;
+  int parity_ = -1;
   bcg_field* f_ = nullptr;
   mutable std::vector<block_fermion<N_rhs>, blockcg::pinned_allocator<block_fermion<N_rhs>>> host_;
   mutable bool host_valid_ = false, host_dirty_ = false;

@@ -134,6 +134,18 @@ int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int con
 int bcg_field_create(bcg_context* ctx, int m, bcg_field** f);          /* explicit ctor :35 (contents undefined) */
 int bcg_field_destroy(bcg_field* f);
 int bcg_field_width(const bcg_field* f);
+/* Half-volume (parity-compact) fields -- SURVEY.md section 8f-4 / Appendix D.  dirac_op::D couples nearest neighbours only
+ * (inc/dirac_op.hpp:14-21), i.e. sites of opposite parity x_0+x_1+x_2+x_3 (mod 2), so dirac_op::op = mass^2 - D^2
+ * (inc/dirac_op.hpp:36-43) never mixes the two parities and (op + sigma) X = B splits into two independent solves on V/2
+ * sites each.  A half field holds the V/2 local sites of one parity (0 or 1) in the order of the full lattice; every
+ * field primitive, dirac_apply and every solver accept half fields (all operands of a call of the SAME parity; the
+ * solver's work fields are then half fields too: half the device memory of a full-volume solve, twice).
+ * Undivided lattices with even extents only (BCG_ERR_UNSUPPORTED otherwise).  Links stay full-volume. */
+int bcg_field_create_half(bcg_context* ctx, int m, int parity, bcg_field** f);
+int bcg_field_parity(const bcg_field* f);   /* -1: full field; 0 / 1 */
+int64_t bcg_field_sites(const bcg_field* f); /* sites held: V_local or V_local / 2 */
+/* to_half != 0: half = the sites of its parity of `full`; else: those sites of `full` = half (the rest of `full` is kept) */
+int bcg_field_parity_copy(bcg_field* full, bcg_field* half, int to_half);
 /* The reference's fields live in host memory in the layout [site][rhs][colour] (inc/fields.hpp:19-20,28-30) and its
  * drivers read elements there (benchmark.cpp:61-63).  Both transfers convert the layout on the device and pipeline two
  * chunks (conversion kernel of one behind the bus transfer of the other).  Host memory the HIP runtime knows as pinned --
@@ -179,6 +191,8 @@ int bcg_gauge_fill_random(bcg_gauge* g, uint64_t seed);      /* stands in for th
 int bcg_dirac_hop(bcg_context* ctx, const bcg_gauge* g, bcg_field* out, const bcg_field* in);
 /* op :36-43:  out = mass^2 in - D(D(in)).  The reference allocates a temporary per call (:39);
  * here the context owns one scratch field per width. */
+/* out (parity p) = D in (parity 1 - p), half fields: the two off-diagonal blocks of dirac_op::D in the parity basis */
+int bcg_dirac_hop_half(bcg_context* ctx, const bcg_gauge* g, bcg_field* out, const bcg_field* in);
 int bcg_dirac_apply(bcg_context* ctx, const bcg_gauge* g, double mass, bcg_field* out, const bcg_field* in);
 
 /* ---- solver: SBCGrQ (inc/block_solvers.hpp:91-185) ------------------------------------------ */

@@ -216,6 +216,15 @@ def test_multi_gpu_driver_two_ranks_same_idfile_twice(tmp_path):
 
 
 @pytest.mark.gpu
+def test_half_volume_solve_through_the_headers():
+    """blockcg::SBCGrQ_half_volume (two solves on half fields, one per site parity) passes the reference's acceptance test
+    evaluated with the full-volume operator."""
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "half_volume_probe.cpp"), "half_volume_probe")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HALF_VOLUME_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_field_multiplier_overloads_on_the_gpu():
     """Every (double | N x N) multiplier combination of add / rescale_add (inc/fields.hpp:69-90) and a write through
     operator[] (:37) on the drop-in field type, against the same expressions evaluated on the host site by site."""
