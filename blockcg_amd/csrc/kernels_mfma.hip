@@ -298,8 +298,14 @@ __device__ __forceinline__ void gram_step(GramAcc<M>& G, const double2* a, const
 
 // Sum the per-wave fragments of a block in wave order and write partials[block][j*M + i].
 // red: LDS scratch of NW * JB*JB * 2 * 4 * 64 doubles.
+// wt: write-through (sc1) stores -- the partials are handed to another workgroup inside this launch (gram_fold)
+__device__ __forceinline__ void st_partial(double2* p, double2 v, bool wt) {
+  if (wt) st_sc1(p, v);
+  else *p = v;
+}
 template <int M, int NW>
-__device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* red, double2* __restrict__ partials, int tid) {
+__device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* red, double2* __restrict__ partials, int tid,
+                                                 bool wt = false) {
   // one 16 x 16 block of the Gram matrix at a time through a buffer of NW * 8 * 64 doubles (16 KB at four waves): at
   // m = 32 a buffer for all four blocks was 64 KB and left phase B a single block per CU
   constexpr int JB = M / 16;
@@ -323,7 +329,7 @@ __device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* re
         si += red[(w * 8 + 4 + r) * 64 + l];
       }
       const int i = 16 * (q / JB) + (l >> 4) + 4 * r, j = 16 * (q % JB) + (l & 15);
-      partials[static_cast<int64_t>(blockIdx.x) * (M * M) + j * M + i] = make_double2(sr, si);
+      st_partial(partials + static_cast<int64_t>(blockIdx.x) * (M * M) + j * M + i, make_double2(sr, si), wt);
     }
   }
 }
@@ -333,7 +339,8 @@ __device__ __forceinline__ void gram_block_store(const GramAcc<M>& G, double* re
 // the two diagonal blocks s = s' are Gram contributions (even and odd rows), the off-diagonal ones are discarded.  So
 // the whole m = 16 machinery applies unchanged and only this final store differs: G(i,j) = C[i][j] + C[8+i][8+j].
 template <int NW>
-__device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, double* red, double2* __restrict__ partials, int tid) {
+__device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, double* red, double2* __restrict__ partials, int tid,
+                                                       bool wt = false) {
   constexpr int FR = 8;  // doubles per lane
   const int wave = tid >> 6, lane = tid & 63;
   __syncthreads();
@@ -354,7 +361,7 @@ __device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, dou
       si += red[((w * FR) + 4 + r) * 64 + l] + red[((w * FR) + 4 + r + 2) * 64 + l + 8];
     }
     const int i = (l >> 4) + 4 * r, j = l & 7;
-    partials[static_cast<int64_t>(blockIdx.x) * 64 + j * 8 + i] = make_double2(sr, si);
+    st_partial(partials + static_cast<int64_t>(blockIdx.x) * 64 + j * 8 + i, make_double2(sr, si), wt);
   }
 }
 
@@ -363,63 +370,67 @@ __device__ __forceinline__ void gram_block_store_fold8(const GramAcc<16>& G, dou
 // After a block has written partials[blockIdx.x][NV], the LAST block to finish of each of 8 groups (blocks g, g + 8, ...)
 // sums its group's partials in block order into partials[gridDim.x + g], and the last of the 8 groups to finish sums those
 // in group order into `out`: a fixed order whatever the arrival order (bitwise reproducible), no separate reduction
-// launch.  The hand-off between workgroups follows the guide's recipe (every storing wave drains its stores, block
-// barrier, one lane: agent-scope release, ticket; the winner: agent-scope acquire, block barrier, plain loads).
+// launch.  The hand-off between workgroups uses no cache-wide fence (a release would write back every dirty line these
+// kernels have just produced -- measured: +80 us on a 0.22 ms phase B): every handed-off byte is stored write-through
+// (sc1; the callers pass wt = true to gram_block_store), every storing wave drains its stores, a block barrier, ONE lane
+// takes an agent-scope ticket, and the block whose ticket is the last reads the bytes with sc1 loads (the L1 is bypassed,
+// the L2 is the point of coherence for write-through data).
 // tickets: 9 words, zero before the first launch; the final block leaves them zero again.  All threads of the block call it.
+// Sum of n values p[0], p[stride], ... read with sc1 loads, in index order; eight loads in flight at a time (one load and
+// its wait at a time made the fold's tail 128 serial L2 round trips).
+__device__ __forceinline__ double2 sum_sc1(const double2* p, int64_t stride, int n) {
+  double sr = 0.0, si = 0.0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    dv2 r0, r1, r2, r3, r4, r5, r6, r7;
+    const double2* q = p + static_cast<int64_t>(k) * stride;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r0) : "v"(q));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r1) : "v"(q + stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r2) : "v"(q + 2 * stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r3) : "v"(q + 3 * stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r4) : "v"(q + 4 * stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r5) : "v"(q + 5 * stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r6) : "v"(q + 6 * stride));
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r7) : "v"(q + 7 * stride));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : : "memory");
+    sr += r0.x; si += r0.y; sr += r1.x; si += r1.y; sr += r2.x; si += r2.y; sr += r3.x; si += r3.y;
+    sr += r4.x; si += r4.y; sr += r5.x; si += r5.y; sr += r6.x; si += r6.y; sr += r7.x; si += r7.y;
+  }
+  for (; k < n; ++k) {
+    dv2 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p + static_cast<int64_t>(k) * stride) : "memory");
+    sr += r.x;
+    si += r.y;
+  }
+  return make_double2(sr, si);
+}
 template <int NV>
 __device__ __forceinline__ void gram_fold(const GramFold& gf, double2* __restrict__ partials, int tid, int nthreads) {
   if (gf.out == nullptr) return;
   __shared__ int s_role;
   const int nb = gridDim.x, g = blockIdx.x & 7;
   const int in_group = (nb - g + 7) >> 3;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partial stores have reached the L2
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(gf.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_role = t == static_cast<unsigned>(in_group - 1) ? 1 : 0;
-    if (s_role) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
   if (!s_role) return;
   double2* const level2 = partials + static_cast<int64_t>(nb) * NV;
-  for (int v = tid; v < NV; v += nthreads) {
-    double sr = 0.0, si = 0.0;
-    for (int b = g; b < nb; b += 8) {
-      const double2 t = partials[static_cast<int64_t>(b) * NV + v];
-      sr += t.x;
-      si += t.y;
-    }
-    level2[g * NV + v] = make_double2(sr, si);
-  }
+  for (int v = tid; v < NV; v += nthreads)
+    st_sc1(level2 + g * NV + v, sum_sc1(partials + static_cast<int64_t>(g) * NV + v, static_cast<int64_t>(8) * NV, in_group));
   const int groups = nb < 8 ? nb : 8;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(gf.tickets + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_role = t == static_cast<unsigned>(groups - 1) ? 2 : 0;
-    if (s_role) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
   if (s_role != 2) return;
-  for (int v = tid; v < NV; v += nthreads) {
-    double sr = 0.0, si = 0.0;
-    for (int k = 0; k < groups; ++k) {
-      const double2 t = level2[k * NV + v];
-      sr += t.x;
-      si += t.y;
-    }
-    gf.out[v] = make_double2(sr, si);
-  }
+  for (int v = tid; v < NV; v += nthreads) gf.out[v] = sum_sc1(level2 + v, NV, groups);
   if (tid < 9) gf.tickets[tid] = 0u;  // ready for the next launch (stream order makes this visible to it)
 }
 
@@ -500,7 +511,7 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
       q = qn;
     }
   }
-  gram_block_store<M, NW>(G, scratch, partials, tid);
+  gram_block_store<M, NW>(G, scratch, partials, tid, gf.out != nullptr);
   gram_fold<M * M>(gf, partials, tid, NW * 64);
 }
 
@@ -1535,8 +1546,8 @@ __device__ __forceinline__ void hop4c_body(const LatticeDev& lat, const double2*
 #endif
 #undef BCG_STAMP
   if (GRAM) {
-    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
-    else gram_block_store<16, NW>(G, smem, partials, tid);
+    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid, hw.fold.out != nullptr);  // two sites per 16-lane row: see the fold
+    else gram_block_store<16, NW>(G, smem, partials, tid, hw.fold.out != nullptr);
     gram_fold<M * M>(hw.fold, partials, tid, NW * 64);
   }
 }
@@ -2169,8 +2180,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #endif
 #undef BCG_STAMPB
   if (GRAM) {
-    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid);  // two sites per 16-lane row: see the fold
-    else gram_block_store<16, NW>(G, smem, partials, tid);
+    if (M == 8) gram_block_store_fold8<NW>(G, smem, partials, tid, hw.fold.out != nullptr);  // two sites per 16-lane row: see the fold
+    else gram_block_store<16, NW>(G, smem, partials, tid, hw.fold.out != nullptr);
     gram_fold<M * M>(hw.fold, partials, tid, NW * 64);
   }
 #undef BO_F
@@ -2269,7 +2280,7 @@ __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, doub
       gram_step<16>(G, &av, &av);
     }
   }
-  gram_block_store_fold8<NW>(G, scratch, partials, tid);
+  gram_block_store_fold8<NW>(G, scratch, partials, tid, gf.out != nullptr);
   gram_fold<64>(gf, partials, tid, NW * 64);
 }
 
