@@ -789,16 +789,56 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
   if (P->parity >= 0) {  // A restricted to one parity: tmp (other parity) = D P, T = (mass^2 + sigma0) P - D tmp
     if (gram_blocks) *gram_blocks = 0;
     if (T->parity != P->parity) BCG_FAIL(c, BCG_ERR_INVALID, "half-volume operator: result and argument must have the same parity");
+    const int m = P->m;
     bcg_field* tmp;
-    BCG_TRY(get_tmp_half(c, P->m, 1 - P->parity, &tmp));
+    BCG_TRY(get_tmp_half(c, m, 1 - P->parity, &tmp));
+    // the bundle sweep in its checkerboard form (m = 16, compact row a multiple of the tile, patch walk), else the generic kernel
+    bcg::LatticeDev latc = c->lat;
+    latc.L[0] /= 2;
+    latc.V /= 2;
+    for (int mu = 1; mu < 4; ++mu) latc.stride[mu] /= 2;
+    const bool fast = fast_hop(c, m) && (m == 16 || m == 32) && c->ndim == 4 && latc.L[0] > 0 && bcg::hop_can_split_tiles(m, latc);
+    int nb1 = -1, nb2 = -1;
+    if (fast) {
+      BCG_TRY(ensure_scratch(c));
+      bcg::HopWindow w;
+      w.cb = 1;
+      w.cb_parity = tmp->parity;
+      {
+        ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2));
+        nb1 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0,
+                                   c->partials, false, kFastBlocks, c->hop_tune, 0, w);
+      }
+      if (nb1 >= 0) {
+        BCG_TRY(check_launch(c, "hop_half"));
+        const bool gram = gram_blocks != nullptr && m == 16;  // the fused product exists at m = 16 (as in the full-volume sweep)
+        bcg::HopTuning tune = c->hop_tune;
+        const bool fold = gram && gram_folded;
+        if (fold) tune.fold = bcg::GramFold{c->dev_gram, c->fold_tickets};
+        w.cb_parity = T->parity;
+        {
+          ProfScope ps(c, gram ? "hop_half_shifted_gram" : "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2));
+          nb2 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
+                                     mass * mass + sigma0, c->partials, gram, kFastBlocks, tune, 0, w);
+        }
+        if (nb2 < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume operator: second stencil rejected after the first ran");
+        BCG_TRY(check_launch(c, "hop_half_shifted"));
+        if (gram) {
+          *gram_blocks = nb2;
+          if (fold) *gram_folded = true;
+        }
+        if (c->profiling) c->prof["stencil_form_k_hop4b_checkerboard"].count += 2;
+        return BCG_OK;
+      }
+    }
     {
-      ProfScope ps(c, "hop_half", alg_bytes(c, P->m, 2, 1, 1, 2));
-      bcg::launch_hop_half(c->stream, P->m, c->lat, tmp->parity, g->U, P->d, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
+      ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2));
+      bcg::launch_hop_half(c->stream, m, c->lat, tmp->parity, g->U, P->d, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
     }
     BCG_TRY(check_launch(c, "hop_half"));
     {
-      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, P->m, 3, 1, 1, 2));
-      bcg::launch_hop_half(c->stream, P->m, c->lat, T->parity, g->U, tmp->d, T->d, bcg::HOP_SHIFTED, P->d, mass * mass + sigma0);
+      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2));
+      bcg::launch_hop_half(c->stream, m, c->lat, T->parity, g->U, tmp->d, T->d, bcg::HOP_SHIFTED, P->d, mass * mass + sigma0);
     }
     return check_launch(c, "hop_half_shifted");
   }

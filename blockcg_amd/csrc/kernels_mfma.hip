@@ -1602,7 +1602,7 @@ k_hop4c_interior(LatticeDev lat, const double2* __restrict__ U, const double2* _
 // of LDS: m = 16 (73.7 KB per block) and m = 32 (70 KB); at m = 8 (two images: 100 KB) one image, own links only.
 __host__ __device__ constexpr bool hop4b_share_images(int m) { return m >= 16; }
 
-template <int M, int MODE, bool GRAM, bool RING>
+template <int M, int MODE, bool GRAM, bool RING, bool CB = false>
 __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2* __restrict__ U,
                                            const double2* __restrict__ Ughost, const double2* __restrict__ in,
                                            const double2* __restrict__ ghost, double2* __restrict__ out,
@@ -1613,15 +1613,24 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
   constexpr bool RESID = MODE == HOP_RESID;  // no output: the Gram product of (c0 p - D in - b) with itself, b passed as `out`
   static_assert(!RESID || (GRAM && !RING), "the residual form accumulates a Gram product and is not ring-addressed");
+  // CB (checkerboard, half-volume fields -- kernels_generic.hip "Half-volume fields"): `in` holds the sites of one parity,
+  // `out` / `p` those of the other, both in the compact order, and `lat` is the COMPACT lattice (L[0] = half the row).  A
+  // row (x1, x2, x3) of the output has r = (x1 + x2 + x3 + parity of out) & 1 and its compact site k is x0 = 2 k + r; the
+  // input row at the same (x1, x2, x3) holds x0 = 2 k + 1 - r.  Neighbours in directions 1..3 keep k; in direction 0 the
+  // forward one is input site k + r, the backward one k - 1 + r.  Links stay in the full-lattice layout: a wave's sites are
+  // every other site of a full row, no backward link is another output site's forward link (so all four directions'
+  // backward links are gathered, none carried or shared), and U_0(x - 0) is gathered like the others.  Undivided lattices.
+  static_assert(!CB || (!RING && !RESID), "checkerboard form: whole-field launches only");
   constexpr int SPW = 64 / M;              // sites per wave = tile extent in x0
   constexpr int NW = 4;
   constexpr int CS = (SPW + 2) * 3 * M;    // one wave's row slot: halo site, SPW sites, halo site (complex numbers)
   constexpr int NFW = (SPW + 1) * 36;      // link image of a wave: slot of the site to the left (U_0 only), forward links
-  constexpr int NBW = 3 * SPW * 9;         // ... backward links, directions 1..3
+  constexpr int NBW = (CB ? 4 : 3) * SPW * 9;  // ... backward links, directions 1..3 (CB: and direction 0, behind them)
   constexpr int LSTAGE = NFW + NBW;
   constexpr int RFW = (SPW * 36 + 63) / 64;
   constexpr int RBK = (SPW * 9 + 63) / 64;
-  constexpr bool SHARE = hop4b_share_images(M);
+  constexpr bool SHARE = hop4b_share_images(M);   // two link images per wave (LDS-DMA into the one not being read)
+  constexpr bool PARTNER = SHARE && !CB;           // in-bundle backward links from the partner waves, U_3(x - 3) carried
   constexpr bool ROWDMA = BCG_HOP4B_ROWDMA != 0;  // +x3 row (own sites + halo sites) by LDS-DMA into its slot
   // PREO (with ROWDMA): the two rows that leave the bundle are loaded ONE STEP AHEAD into registers, so that the first
   // three directions of a step wait for nothing and the step's only fresh data -- the +x3 row -- has them to arrive in
@@ -1836,6 +1845,42 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           if (lane + 64 * k < SPW * 9) glds16_link(q3 + BO_SEL(k_b3, k), img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
       }
     };
+    // CB: the links of the wave's SPW output sites of slice x3 -- every other site of a full-lattice row -- by LDS-DMA into
+    // image(x3): forward links (one 36-entry record per site, the records 2 apart), then the backward links of all four
+    // directions, each U_mu of the full-lattice site x - mu (periodic; the lattice is undivided).
+    auto dma_links_cb = [&](int x3) __attribute__((always_inline)) {
+      const int L0f = 2 * L0;
+      const int rr = (x1 + x2 + x3 + win.cb_parity) & 1;           // x0 = 2 k + rr on this row
+      const int64_t rowf = static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * (x2 + static_cast<int64_t>(L2) * x3));
+      const int xf0 = 2 * x0b + rr;                                  // full x0 of the wave's first site
+      const char* const ub_ = reinterpret_cast<const char*>(U);
+      const unsigned img = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave)));
+      // forward: element e = lane + 64 k -> site e / 36, entry e % 36
+#pragma unroll
+      for (int k = 0; k < RFW; ++k) {
+        const int e = lane + 64 * k;
+        if (e < SPW * 36)
+          glds16_link(ub_ + (rowf + xf0 + 2 * (e / 36)) * (36 * 16) + (e % 36) * 16, img + (36 + 64 * k) * 16);
+      }
+      // backward, direction mu: element e -> site s = e / 9, entry e % 9 of U_mu at the full site of x - mu
+      const int x1m = x1 > 0 ? x1 - 1 : L1 - 1, x2m = x2 > 0 ? x2 - 1 : L2 - 1, x3m = x3 > 0 ? x3 - 1 : L3 - 1;
+      const int64_t row1 = static_cast<int64_t>(L0f) * (x1m + static_cast<int64_t>(L1) * (x2 + static_cast<int64_t>(L2) * x3));
+      const int64_t row2 = static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * (x2m + static_cast<int64_t>(L2) * x3));
+      const int64_t row3 = static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * (x2 + static_cast<int64_t>(L2) * x3m));
+#pragma unroll
+      for (int k = 0; k < RBK; ++k) {
+        const int e = lane + 64 * k;
+        if (e < SPW * 9) {
+          const int xs = xf0 + 2 * (e / 9);
+          const unsigned eo = (e % 9) * 16;
+          glds16_link(ub_ + ((row1 + xs) * 4 + 1) * (9 * 16) + eo, img + (NFW + 64 * k) * 16);
+          glds16_link(ub_ + ((row2 + xs) * 4 + 2) * (9 * 16) + eo, img + (NFW + SPW * 9 + 64 * k) * 16);
+          glds16_link(ub_ + ((row3 + xs) * 4 + 3) * (9 * 16) + eo, img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
+          const int xm = xs > 0 ? xs - 1 : L0f - 1;
+          glds16_link(ub_ + ((rowf + xm) * 4 + 0) * (9 * 16) + eo, img + (NFW + 3 * SPW * 9 + 64 * k) * 16);
+        }
+      }
+    };
     // U_3(x - 3) of slice x3 = U_3 of the wave's own sites in image(x3 - 1): copied into image(x3)
     auto park_u3 = [&](int x3) __attribute__((always_inline)) {
       const dv2* const Lo = image(x3 - 1, wave);
@@ -1914,7 +1959,10 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       dv2* const Cm = Cbase + (((lo + 1) & 1) * NW + wave) * CS;
 #pragma unroll
       for (int c = 0; c < 3; ++c) Cm[co + c * M] = *reinterpret_cast<const dv2*>(own + voff + c * M * 16);
-      if (SHARE) {
+      if (CB) {
+        dma_links_cb(lo);
+        asm volatile("s_waitcnt vmcnt(0)");
+      } else if (SHARE) {
         dma_links(lo, true);
         asm volatile("s_waitcnt vmcnt(0)");  // landed before the first step's barrier (hipcc does not count them)
       } else {
@@ -1961,14 +2009,16 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
       BCG_STAMPB(1)   // barrier
       if (x3 + 1 < x3_end) {
-        if (SHARE) dma_links(x3 + 1, false);   // into the other image, in front of this step's ordinary loads
+        if (CB) dma_links_cb(x3 + 1);
+        else if (SHARE) dma_links(x3 + 1, false);   // into the other image, in front of this step's ordinary loads
         else fetch_links(x3 + 1, false);       // parked at the end of this step
       }
       const dv2* const Lf = image(x3, wave);
       const dv2* const Lb = Lf + NFW;
       // backward links of directions 1, 2: own image (row outside the bundle) or the partner wave's forward links
-      const dv2* const ub1 = (SHARE && e1) ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
-      const dv2* const ub2 = (SHARE && e2) ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
+      const dv2* const ub1 = (PARTNER && e1) ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
+      const dv2* const ub2 = (PARTNER && e2) ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
+      const int rr = CB ? (x1 + x2 + x3 + win.cb_parity) & 1 : 0;  // CB: this row's x0 = 2 k + rr
       const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;       // centre rows of the four waves (this slice)
       dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;  // this wave's slot for slice x3 + 1; holds slice x3 - 1
       double2 f[4][3], bk[4][3];
@@ -2050,7 +2100,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       const dv2* const Cp2 = Cc + (wave ^ 2) * CS;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const dv2 a = Cown[co + 3 * M + c * M], b = Cown[co - 3 * M + c * M];
+        // full lattice: sites k + 1 and k - 1 of the own row; CB: input sites k + rr and k - 1 + rr
+        const dv2 a = Cown[co + (CB ? rr : 1) * 3 * M + c * M], b = Cown[co + (CB ? rr - 1 : -1) * 3 * M + c * M];
         f[0][c] = make_double2(a.x, a.y);
         bk[0][c] = make_double2(b.x, b.y);
       }
@@ -2069,7 +2120,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = make_double2(v.x, v.y); bk[2][c] = o2[c]; }
       }
       double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-      const int x0 = x0b + sw;
+      const int x0 = CB ? 2 * (x0b + sw) + rr : x0b + sw;
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
@@ -2089,7 +2140,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
         const double eta = (par & 1) ? -1.0 : 1.0;
         const dv2* uf = Lf + (sw + 1) * 36 + mu * 9;
-        const dv2* ub = mu == 0 ? Lf + sw * 36 : (mu == 1 ? ub1 : (mu == 2 ? ub2 : Lb + (2 * SPW + sw) * 9));
+        const dv2* ub = mu == 0 ? (CB ? Lb + (3 * SPW + sw) * 9 : Lf + sw * 36)
+                                : (mu == 1 ? ub1 : (mu == 2 ? ub2 : Lb + (2 * SPW + sw) * 9));
         double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -2120,7 +2172,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       // pacing atomics are issued behind it and are never waited for inside the step: k_hop4c parks at the top of the
       // next tile and drains them there, 13 % of its time.
       if (x3 + 1 < x3_end) {
-        if (SHARE) park_u3(x3 + 1);
+        if (CB) {}  // nothing to carry: every backward link was gathered
+        else if (SHARE) park_u3(x3 + 1);
         else park_links(x3 + 1, false);
       }
       // park the +x3 row (own sites and halo) as the next step's centre row
@@ -2188,12 +2241,12 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #undef BO_SEL
 }
 
-template <int M, int MODE, bool GRAM, bool RING>
+template <int M, int MODE, bool GRAM, bool RING, bool CB = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_hop4b(
     LatticeDev lat, const double2* __restrict__ U, const double2* __restrict__ Ughost, const double2* __restrict__ in,
     const double2* __restrict__ ghost, double2* __restrict__ out, const double2* __restrict__ p, double c0,
     double2* __restrict__ partials, HopWalk hw, HopWindow win) {
-  hop4b_body<M, MODE, GRAM, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
+  hop4b_body<M, MODE, GRAM, RING, CB>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
 }
 
 #ifdef BCG_PROBE  // tuning aid: compile only the probed stencil instantiations (seconds instead of minutes)
@@ -2394,7 +2447,10 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
   const int SPB = 4 * (64 / m);
   // patch extent in x0: one tile unless set (a patch slice then has p1*p2 = 64 tiles = the blocks of an XCD at every width)
   const int walk = tune.patch_walk ? 3 : 0, p0 = tune.patch[0] > 0 ? tune.patch[0] : SPB, p1 = tune.patch[1], p2 = tune.patch[2];
-  if (win.x3_n <= 0) win = HopWindow{0, lat.L[3], win.ring};
+  if (win.x3_n <= 0) {
+    win.x3_lo = 0;
+    win.x3_n = lat.L[3];
+  }
   if (win.x3_lo < 0 || win.x3_lo + win.x3_n > lat.L[3]) return pl;
   // ring addressing: whole tiles only (no interior/boundary split), direction 3 undivided, ring | L3
   if (win.ring > 0 && (cls != 0 || lat.split[3] || win.ring < 3 || lat.L[3] % win.ring != 0)) return pl;
@@ -2456,6 +2512,33 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   if (pl.list && grid == 0) return 0;  // no boundary tiles
   const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
+  // checkerboard form (half-volume fields): the bundle sweep at m = 16 on an undivided lattice, or nothing (the caller
+  // then runs the generic half-volume kernel)
+  if (win.cb) {
+    // m = 16 and 32: the widths with two link images per wave (the DMA needs the one that is not being read)
+    if (!hop4b_share_images(M) || (gram && M != 16) || mode == HOP_RESID || win.ring > 0 || cls != 0 || lat.split[0] ||
+        lat.split[1] || lat.split[2] || lat.split[3] || !bundle_ok(M, lat, tune, pl, cls, true))
+      return -1;
+    constexpr int MC = hop4b_share_images(M) ? M : 16;  // (never launched for the other widths)
+    HopWalk hwb = hw;
+    if (tune.sync.bundle_window > 0 && hw.sync) hwb.sync_window = tune.sync.bundle_window;
+    else hwb.sync = nullptr;
+    if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
+    constexpr int SPWc = 64 / MC;
+    const size_t lds_u = sizeof(double2) * (2 * 4 * ((SPWc + 2) * 3 * MC) + 2 * 4 * ((SPWc + 1) * 36 + 4 * SPWc * 9));
+    const size_t lds = lds_u > lds_g ? lds_u : lds_g;
+#define BCG_LAUNCH4B_CB(MM, MD, GR)                                                                                      \
+  do {                                                                                                              \
+    allow_lds(k_hop4b<MM, MD, GR, false, true>, lds);                                                               \
+    hipLaunchKernelGGL((k_hop4b<MM, MD, GR, false, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, p, \
+                       c0, partials, hwb, win);                                                                     \
+  } while (0)
+    if (mode == HOP_PLAIN) BCG_LAUNCH4B_CB(MC, HOP_PLAIN, false);
+    else if (gram) BCG_LAUNCH4B_CB(16, HOP_SHIFTED, true);
+    else BCG_LAUNCH4B_CB(MC, HOP_SHIFTED, false);
+#undef BCG_LAUNCH4B_CB
+    return grid;
+  }
   // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
   if (bundle_ok(M, lat, tune, pl, cls, mode == HOP_PLAIN)) {
     HopWalk hwb = hw;  // pacing of the bundle sweep: its own window (default none)
@@ -2576,7 +2659,7 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
     if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
     return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
   }
-  if (win.x3_n > 0 || win.ring > 0 || mode == HOP_RESID) return -1;  // specialised kernel only
+  if (win.x3_n > 0 || win.ring > 0 || win.cb || mode == HOP_RESID) return -1;  // specialised kernel only
   if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles
   const int64_t ntiles = (lat.V + spb - 1) / spb;
   const int grid = grid_tiles(ntiles, 1, max_blocks);

@@ -67,6 +67,9 @@ struct HopTuning {
 struct HopWindow {
   int x3_lo = 0, x3_n = 0;  // x3_n = 0: all slices
   int ring = 0;
+  // Checkerboard form (half-volume fields): cb = 1, `lat` is the COMPACT lattice (L[0] halved), `out`/`p` hold the sites of
+  // parity cb_parity, `in` those of the other parity.  k_hop4b, whole launches on an undivided lattice only.
+  int cb = 0, cb_parity = 0;
 };
 
 // Stencil; with gram (m = 16, HOP_SHIFTED) also writes partials of p^dagger out.  Returns blocks used.

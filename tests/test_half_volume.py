@@ -105,3 +105,75 @@ def test_half_volume_memory_and_rejections():
         bc.block_fermion_field(bc.Context([6, 3, 4, 4]), 4, parity=0)
     full = bc.block_fermion_field(ctx, 16)
     assert ctx.lib.bcg_field_parity(full.h) == -1
+
+
+@pytest.mark.parametrize("m,dims,patch", [(16, [64, 8, 8, 6], "16,2,2"), (32, [32, 8, 8, 4], "8,2,2")], ids=["m16", "m32"])
+@pytest.mark.parametrize("sync", ["0", "4"])
+def test_checkerboard_bundle_sweep_matches_generic_and_oracle(orc, m, dims, patch, sync, monkeypatch):
+    """The fast form of the half-volume operator -- k_hop4b in its checkerboard mode (m = 16: 2 x 2 column bundles on the
+    compact lattice, links of every other full-lattice site by LDS-DMA, all four directions' backward links gathered, fused
+    Gram product folded in the kernel) -- on a lattice small enough for the whole-lattice oracle, with small patches so that
+    the column walk applies; against the oracle and against the generic half-volume kernel."""
+    import blockcg_amd as bc
+    monkeypatch.setenv("BCG_HOP_PATCH", patch)
+    monkeypatch.setenv("BCG_HOP_BLOCKS", "32")
+    monkeypatch.setenv("BCG_HOP_BUNDLE_SYNC", sync)
+    mass = 0.3
+    shifts, iters = [0.0, 0.05], 4
+    V = int(np.prod(dims))
+    U = orc.fill_gauge(dims, 31)
+    Fh = orc.fill_field(m, V, 32)
+    Ah = orc.dirac_apply(U, dims, mass, Fh)
+    masks = _parity_masks(dims)
+    results = {}
+    for generic in (False, True):
+        ctx = bc.Context(dims)
+        ctx.force_generic(generic)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        per_parity = []
+        for par in (0, 1):
+            B = bc.block_fermion_field(ctx, m, parity=par).setRandom(seed=32)
+            out = bc.block_fermion_field(ctx, m, parity=par)
+            D.op(out, B)
+            assert rel_err(out.download(), Ah[masks[par]]) < TOL_KERNEL, (generic, par)
+            X = [bc.block_fermion_field(ctx, m, parity=par) for _ in shifts]
+            info = bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters, return_info=True)
+            per_parity.append((info["trace"], [x.download() for x in X]))
+        prof = ctx.profile()
+        assert ("stencil_form_k_hop4b_checkerboard" in prof) == (not generic), prof.keys()
+        if not generic and m == 16:
+            assert "hop_half_shifted_gram" in prof and "gram_pair" not in prof  # the fused product, folded in the kernel
+        results[generic] = per_parity
+    for par in (0, 1):
+        for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+            assert rel_err(results[False][par][0][key], results[True][par][0][key]) < 1e-10, (par, key)
+        for s in range(len(shifts)):
+            assert rel_err(results[False][par][1][s], results[True][par][1][s]) < 1e-11
+
+
+def test_checkerboard_operator_at_full_size_sampled(orc):
+    """The production geometry of the half-volume operator (64^4, m = 16: default patches, 512 blocks, paced) at sampled
+    sites against the oracle's per-site evaluation from the generator (tests/test_fullsize_parity.py's method)."""
+    import blockcg_amd as bc
+    dims, m, mass = [64, 64, 64, 64], 16, 1e-3
+    ctx = bc.Context(dims)
+    ctx.profiling(True)
+    D = bc.dirac_op(ctx, mass, seed=41)
+    rng = np.random.default_rng(5)
+    for par in (0, 1):
+        F = bc.block_fermion_field(ctx, m, parity=par).setRandom(seed=42)
+        out = bc.block_fermion_field(ctx, m, parity=par)
+        D.op(out, F)
+        # half sites: corners of the compact lattice, first / last slice, random ones
+        h = np.unique(np.concatenate([rng.integers(0, ctx.V // 2, 600), np.arange(0, 64), np.arange(ctx.V // 2 - 64, ctx.V // 2),
+                                      np.arange(32 * 64 * 64 - 40, 32 * 64 * 64 + 40)]))
+        k, rest = h % 32, h // 32
+        x1, x2, x3 = rest % 64, (rest // 64) % 64, rest // (64 * 64)
+        x0 = 2 * k + ((x1 + x2 + x3 + par) & 1)
+        full = x0 + 64 * (x1 + 64 * (x2 + 64 * x3))
+        want = orc.apply_sampled(m, dims, 41, 42, mass, full)
+        got = out.download_sites(h)
+        err = np.abs(got - want).reshape(len(h), -1).max(axis=1) / np.abs(want).max()
+        assert err.max() < 1e-13, (par, err.max())
+    assert "stencil_form_k_hop4b_checkerboard" in ctx.profile()
