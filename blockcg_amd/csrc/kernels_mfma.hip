@@ -20,6 +20,8 @@
 // free for addressing and the loads/stores, and the kernels remain HBM-bound.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "kernels_mfma.hpp"
 
@@ -151,6 +153,57 @@ __device__ __forceinline__ void tile_store(const Tile<M>& t, double2* __restrict
   if (ok) {
 #pragma unroll
     for (int s = 0; s < M / 4; ++s) p[4 * s] = t.v[s];
+  }
+}
+
+
+// ---- the same tile moved as CONTIGUOUS memory ----------------------------------------------------------------------
+// The MFMA ownership above makes every load / store instruction of a wave 16 separate 64-byte pieces (one per row).  A
+// copy kernel with that shape reaches 5.2 TB/s on nine streams where 1 KB-contiguous instructions reach 6.3
+// (tools/microbench/access_shape.hip, profiles/r03_access_shape_microbench.txt).  So the row kernels move a tile as the
+// 16 M contiguous elements it is -- instruction k of M / 4: element e = lane + 64 k, i.e. row e / M, column e % M -- and
+// change ownership through a per-wave LDS buffer of 16 rows x (16 M + 16) bytes (the padding makes both sides
+// conflict-free); the same wave writes and reads it, so LDS ordering suffices.
+template <int M>
+__device__ __forceinline__ void tile_load_lin(Tile<M>& c, const double2* __restrict__ f, int64_t tile, int64_t rows, int lane) {
+  const double2* p = f + tile * (16 * M);
+#pragma unroll
+  for (int k = 0; k < M / 4; ++k) {
+    const int e = lane + 64 * k;
+    c.v[k] = tile * 16 + e / M < rows ? p[e] : make_double2(0.0, 0.0);
+  }
+}
+template <int M>
+__device__ __forceinline__ void tile_store_lin(const Tile<M>& c, double2* __restrict__ f, int64_t tile, int64_t rows, int lane) {
+  double2* p = f + tile * (16 * M);
+#pragma unroll
+  for (int k = 0; k < M / 4; ++k) {
+    const int e = lane + 64 * k;
+    if (tile * 16 + e / M < rows) p[e] = c.v[k];
+  }
+}
+template <int M>
+__device__ __forceinline__ void lin_to_mfma(Tile<M>& t, double* tw, int lane) {
+  constexpr int TLD = 2 * M + 2;
+#pragma unroll
+  for (int k = 0; k < M / 4; ++k) {
+    const int e = lane + 64 * k;
+    *reinterpret_cast<double2*>(tw + (e / M) * TLD + 2 * (e % M)) = t.v[k];
+  }
+  const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < M / 4; ++s) t.v[s] = *reinterpret_cast<const double2*>(tw + r * TLD + 2 * (4 * s + kq));
+}
+template <int M>
+__device__ __forceinline__ void mfma_to_lin(Tile<M>& t, double* tw, int lane) {
+  constexpr int TLD = 2 * M + 2;
+  const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = t.v[s];
+#pragma unroll
+  for (int k = 0; k < M / 4; ++k) {
+    const int e = lane + 64 * k;
+    t.v[k] = *reinterpret_cast<const double2*>(tw + (e / M) * TLD + 2 * (e % M));
   }
 }
 
@@ -468,6 +521,15 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
 #else
   constexpr bool AHEAD = false;
 #endif
+  // LINB (m = 16): T and Q are loaded as contiguous memory and change ownership through the wave's buffer; the new Q is
+  // stored from the values the Gram product reads back from that buffer, which ARE the contiguous order (element
+  // lane + 64 g is row 4 g + (lane >> 4), column lane & 15): no extra LDS traffic for the store.
+  // Measured (profiles/r03_contiguous_tile_moves.txt): no gain -- 7.47-7.88 ms against 7.1-7.5 -- so off (BCG_PHASEB_LIN build).
+#ifdef BCG_PHASEB_LIN
+  constexpr bool LINB = M == 16 && !AHEAD;
+#else
+  constexpr bool LINB = false;
+#endif
   Tile<M> t, q;
   if (AHEAD && tile < ntiles) {
     tile_load<M>(t, T, tile * 16 + r, kq, tile * 16 + r < rows);
@@ -476,7 +538,12 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
   for (; tile < ntiles; tile += stride) {
     const int64_t row = tile * 16 + r;
     const bool ok = row < rows;
-    if (!AHEAD) {
+    if (LINB) {
+      tile_load_lin<M>(t, T, tile, rows, lane);
+      tile_load_lin<M>(q, Q, tile, rows, lane);
+      lin_to_mfma<M>(t, tw, lane);
+      lin_to_mfma<M>(q, tw, lane);
+    } else if (!AHEAD) {
       tile_load<M>(t, T, row, kq, ok);
       tile_load<M>(q, Q, row, kq, ok);
     }
@@ -493,17 +560,19 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
     tile_from_acc<M>(q, A);
-    tile_store<M>(q, Q, row, kq, ok);
+    if (!LINB) tile_store<M>(q, Q, row, kq, ok);
     // transpose the new tile through LDS: write (r, j = 4s+kq), read (row = 4g + (l>>4), j = l&15 + 16 jb)
 #pragma unroll
     for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = q.v[s];
     // same wave wrote and reads: no barrier needed, only LDS ordering (ds ops of one wave are in order)
+    double2* const qtile = Q + tile * (16 * M);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       double2 a[JB];
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb)
         a[jb] = *reinterpret_cast<const double2*>(tw + (4 * g + (lane >> 4)) * TLD + 2 * (16 * jb + (lane & 15)));
+      if (LINB && tile * 16 + 4 * g + (lane >> 4) < rows) qtile[lane + 64 * g] = a[0];
       gram_step<M>(G, a, a);
     }
     if (AHEAD && tile + stride < ntiles) {
@@ -528,8 +597,9 @@ struct ShiftPtrs {
 // 32 VGPRs, the prefetch would push the kernel to one wave per SIMD, and one launch takes a single shift anyway.
 // NW: waves per block.  At m = 32 a coefficient matrix is 16.6 KB of LDS; one block of 8 waves per CU (instead of two
 // of 4) shares 9 matrices -- Rinv and four shifts -- so that 8 shifts are two launches and Q is read twice, not five times.
-template <int M, bool PREFETCH, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
+template <int M, bool PREFETCH, int NW = 4, bool LIN = false>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(LIN ? 4 : 1)))  // LIN: two 8-wave blocks per CU
+k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
                                                     const double2* __restrict__ mats, int apply_rinv) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
@@ -541,46 +611,66 @@ __global__ void __launch_bounds__(NW * 64) k_phaseC(int64_t rows, double2* __res
   for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k + off) * M * M, tid, NW * 64);
   __syncthreads();
   const double* const smat = smem - off * MD;  // slot of mats[i] = smat + i * MD
+  // LIN: tiles move as contiguous memory and change ownership through this wave's LDS buffer (tile_load_lin ...)
+  double* const tw = smem + nmat * MD + wave * 16 * (2 * M + 2);
   const int r = lane & 15, kq = lane >> 4;
   const int64_t ntiles = (rows + 15) / 16;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
     const int64_t row = tile * 16 + r;
     const bool ok = row < rows;
+    auto load = [&](Tile<M>& t, const double2* f) __attribute__((always_inline)) {
+      if (LIN) tile_load_lin<M>(t, f, tile, rows, lane);
+      else tile_load<M>(t, f, row, kq, ok);
+    };
+    auto store = [&](Tile<M>& t, double2* f) __attribute__((always_inline)) {  // t is left in the stored layout
+      if (LIN) {
+        mfma_to_lin<M>(t, tw, lane);
+        tile_store_lin<M>(t, f, tile, rows, lane);
+      } else {
+        tile_store<M>(t, f, row, kq, ok);
+      }
+    };
     Tile<M> q;
-    tile_load<M>(q, Q, row, kq, ok);
+    load(q, Q);
     Tile<M> p, x;
     if (nshift > 0) {
-      tile_load<M>(p, sp.P[0], row, kq, ok);
-      tile_load<M>(x, sp.X[0], row, kq, ok);
+      load(p, sp.P[0]);
+      load(x, sp.X[0]);
     }
+    if (LIN) lin_to_mfma<M>(q, tw, lane);
     if (apply_rinv) {
       Acc<M> A;
       acc_zero<M>(A);
       rmul_acc<M>(A, q, smem, lane);
       tile_from_acc<M>(q, A);
-      tile_store<M>(q, Q, row, kq, ok);
+      Tile<M> qs = q;
+      store(qs, Q);
     }
     for (int s = 0; s < nshift; ++s) {
       Tile<M> pn, xn;
       if (PREFETCH && s + 1 < nshift) {  // prefetch the next shift's tiles while this one computes
-        tile_load<M>(pn, sp.P[s + 1], row, kq, ok);
-        tile_load<M>(xn, sp.X[s + 1], row, kq, ok);
+        load(pn, sp.P[s + 1]);
+        load(xn, sp.X[s + 1]);
+      }
+      if (LIN) {
+        lin_to_mfma<M>(p, tw, lane);
+        lin_to_mfma<M>(x, tw, lane);
       }
       Acc<M> AX, AP;
       acc_from_tile<M>(AX, x);
       acc_from_tile<M>(AP, q);
       rmul_acc2<M>(AX, smat + (1 + 2 * s) * MD, AP, smat + (2 + 2 * s) * MD, p, lane);
       tile_from_acc<M>(x, AX);
-      tile_store<M>(x, sp.X[s], row, kq, ok);
+      store(x, sp.X[s]);
       tile_from_acc<M>(p, AP);
-      tile_store<M>(p, sp.P[s], row, kq, ok);
+      store(p, sp.P[s]);
       if (s + 1 < nshift) {
         if (PREFETCH) {
           p = pn;
           x = xn;
         } else {
-          tile_load<M>(p, sp.P[s + 1], row, kq, ok);
-          tile_load<M>(x, sp.X[s + 1], row, kq, ok);
+          load(p, sp.P[s + 1]);
+          load(x, sp.X[s + 1]);
         }
       }
     }
@@ -2385,9 +2475,21 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
     hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
   } else if (m == 16) {
     constexpr int M = 16;
-    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
-    allow_lds(k_phaseC<M, true>, lds);
-    hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    // contiguous tile moves (LIN, BCG_PHASEC_LIN=1): 8-wave blocks, so that the 9 matrices (38 KB) are shared by eight
+    // per-wave ownership buffers (34.8 KB) and two blocks = 16 waves still fit a CU (145.6 KB).  Off by default: a copy
+    // kernel loses 17 % to the 64-byte-piece shape (tools/microbench/access_shape.hip) but phase C does not -- 38.85 ms
+    // with contiguous moves, 38.88 without, alternating runs on one device (profiles/r03_contiguous_tile_moves.txt).
+    static const bool lin = std::getenv("BCG_PHASEC_LIN") != nullptr && std::atoi(std::getenv("BCG_PHASEC_LIN")) != 0;
+    if (lin) {
+      const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * nmat + 8 * 16 * (2 * M + 2));
+      const int grid8 = grid_tiles((rows + 15) / 16, 8, max_blocks / 2 > 0 ? max_blocks / 2 : 1);
+      allow_lds(k_phaseC<M, true, 8, true>, lds);
+      hipLaunchKernelGGL((k_phaseC<M, true, 8, true>), dim3(grid8), dim3(512), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    } else {
+      const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
+      allow_lds(k_phaseC<M, true>, lds);
+      hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
+    }
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
