@@ -860,20 +860,33 @@ int phase_A(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_
 
 // Phase B: Q -= T alpha ; G2 = Q^dagger Q   (:148 and the Gram half of :152)
 int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double b, bcg::RmulMode mode, const char* name);
-int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha, CMat& G2) {
+// Deferred normalisation of Q (widths with both fused row kernels and room for a second matrix in phase B's LDS: m = 8,
+// 16).  The reference stores Q rho^-1 (:152, multiply_upper_triangular_inverse_RHS) and reads it back twice: for the P
+// updates (:158, :177) and for the next iteration's Q -= T alpha (:148).  Here phase C forms Q rho^-1 in registers for
+// the P updates and does NOT write it; the un-normalised Q stays in memory and the next phase B multiplies it by the same
+// rho^-1 (same kernel arithmetic, same order: bit-identical iterates) before subtracting T alpha.  One field pass less per
+// iteration: (1 + 4 S) s in phase C instead of (2 + 4 S) s.  BCG_LAZY_Q=0 switches it off.
+bool lazy_q_width(const bcg_context* c, int m) {
+  return c->lazy_q && fast_rows(c, m) && fast_rmul(c, m) && (m == 8 || m == 16);
+}
+
+// rinv_prev: the stored Q is the previous iteration's un-normalised block, to be multiplied by this first (nullptr: Q as it is)
+int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha, CMat& G2, const CMat* rinv_prev = nullptr) {
   const int m = Q->m;
   if (!fast_rows(c, m)) {
     BCG_TRY(rmul(c, Q, T, -alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));
     return gram(c, Q, Q, G2);
   }
   const CMat na = -alpha;
+  const CMat* two[2] = {&na, rinv_prev};
   const double2* Md;
-  BCG_TRY(upload_mat(c, na, &Md));
+  BCG_TRY(upload_mats(c, m, two, rinv_prev ? 2 : 1, &Md));
   int nb;
   {
     ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
     nb = bcg::launch_phaseB(c->stream, m, rows_of(Q), Q->d, T->d, Md, c->partials, c->row_blocks_B,
-                            bcg::GramFold{c->dev_gram, c->fold_tickets});
+                            bcg::GramFold{c->dev_gram, c->fold_tickets},
+                            rinv_prev ? Md + static_cast<size_t>(m) * m : nullptr);
   }
   BCG_TRY(check_launch(c, "phaseB"));
   return finish_gram(c, m, nb, G2, true, /*folded=*/true);
@@ -882,8 +895,9 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
 // Phase C: Q <- Q rho^{-1} ; X_s += P_s A_s ; P_s <- P_s B_s + Q for the n active shifts
 // (:152 second half, :145, :158, :175, :177)
 int trisolve(bcg_context* c, bcg_field* y, const CMat& R);
+// rinv_out != nullptr (lazy_q_width): Q rho^-1 is used but not stored; *rinv_out = rho^-1 for the next phase B
 int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, bcg_field* const* P, int n,
-            const std::vector<CMat>& A, const std::vector<CMat>& Bm) {
+            const std::vector<CMat>& A, const std::vector<CMat>& Bm, CMat* rinv_out = nullptr) {
   const int m = Q->m;
   if (!fast_rmul(c, m)) {
     BCG_TRY(trisolve(c, Q, rho));
@@ -894,6 +908,7 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     return BCG_OK;
   }
   const CMat Rinv = bcg::upper_triangular_inverse(rho);
+  if (rinv_out) *rinv_out = Rinv;
   for (int s0 = 0, first = 1, per = 0; first || s0 < n; s0 += per, first = 0) {
     per = bcg::phaseC_max_shifts(m, first != 0);
     const int ns = std::min(per, n - s0);
@@ -911,8 +926,8 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
     {
       // the launch that applies rho^-1 reads and writes Q; a later launch of the same iteration (m = 32) re-reads it
-      ProfScope ps(c, "phaseC", alg_bytes(c, m, (first ? 2 : 1) + 4 * ns));
-      bcg::launch_phaseC(c->stream, m, rows_of(Q), Q->d, Xp, Pp, ns, Md, first, c->row_blocks_C);
+      ProfScope ps(c, "phaseC", alg_bytes(c, m, (first && !rinv_out ? 2 : 1) + 4 * ns));
+      bcg::launch_phaseC(c->stream, m, rows_of(Q), Q->d, Xp, Pp, ns, Md, rinv_out ? 2 : first, c->row_blocks_C);
     }
     BCG_TRY(check_launch(c, "phaseC"));
   }
@@ -1010,6 +1025,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
+  if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
@@ -1155,6 +1171,7 @@ const char* bcg_profile_json(bcg_context* c) {
   if (!c) return "{}";
   (void)stream_sync(c);
   std::ostringstream os;
+  os.precision(15);
   os << "{";
   bool first = true;
   for (auto& kv : c->prof) {
@@ -1743,6 +1760,8 @@ struct bcg_sbcgrq_state {
   std::vector<double> b_norm;
   double residual = 1.0;
   int iter = 0;
+  CMat q_rinv;          // deferred normalisation (lazy_q_width): the stored Q times this is the reference's Q
+  bool q_lazy = false;
 };
 
 namespace {
@@ -1771,7 +1790,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
   const CMat alpha_delta = st->alpha * st->delta;        // :145 uses delta of the previous iteration
   // Q -= T alpha ; Gram matrix of the new Q                                  :148, :152
   CMat G2;
-  BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2));      // global reduction #2
+  BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
   st->rho_old = st->rho;                                 // :150
   if (!G2.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not finite");
   if (!bcg::cholesky_upper(G2, st->rho)) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not positive definite");
@@ -1821,7 +1840,10 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
     if (tr) tr[1 + s] = residual_shift;
     if (residual_shift < st->eps_shifts) --st->n_unconverged;  // :179-181
   }
-  BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef));
+  const bool lazy = lazy_q_width(c, m);
+  BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
+                  lazy ? &st->q_rinv : nullptr));
+  st->q_lazy = lazy;  // from now on the stored Q is un-normalised: Q_true = Q q_rinv
   if (tracing) trace->recorded += 1;
   return BCG_OK;
 }

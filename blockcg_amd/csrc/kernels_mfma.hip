@@ -491,20 +491,25 @@ __device__ __forceinline__ void gram_fold(const GramFold& gf, double2* __restric
 // Phase B:  Q -= T*alpha  (matrix passed as -alpha),  accumulate Q^dagger Q of the NEW Q.
 // ---------------------------------------------------------------------------------------------------
 template <int M>
+// rinv != nullptr (deferred normalisation, see phase_B in blockcg_capi.hip): the stored Q is the previous iteration's
+// un-normalised block; it is multiplied by rinv = rho_prev^-1 first -- the arithmetic phase C used to do before storing it.
 __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials,
-                                                GramFold gf) {
+                                                GramFold gf, const double2* __restrict__ rinv) {
   constexpr int NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row (M*16 + 16 bytes)
   constexpr int JB = M / 16;
   constexpr int RED = NW * 8 * 64;
   constexpr int TRN = NW * 16 * TLD;
+  constexpr int MDs = (MatLds<M>::DOUBLES + 1) & ~1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ml = smem;                                   // MatLds<M>::DOUBLES
-  double* scratch = smem + ((MatLds<M>::DOUBLES + 1) & ~1);  // max(RED, TRN) doubles, 16-B aligned
+  double* Mr = smem + MDs;                             // rinv, when given
+  double* scratch = smem + MDs * (rinv ? 2 : 1);       // max(RED, TRN) doubles, 16-B aligned
   (void)RED; (void)TRN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_matrix<M>(Ml, negalpha, tid, 256);
+  if (rinv) stage_matrix<M>(Mr, rinv, tid, 256);
   __syncthreads();
   const int r = lane & 15, kq = lane >> 4;
   double* tw = scratch + wave * 16 * TLD;
@@ -555,6 +560,12 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
     if (AHEAD && tile + stride < ntiles) {
       tile_load<M>(tn, T, nrow, kq, nok);
       tile_load<M>(qn, Q, nrow, kq, nok);
+    }
+    if (rinv) {  // q <- q rho_prev^-1: exactly what phase C computes for its own use
+      Acc<M> A0;
+      acc_zero<M>(A0);
+      rmul_acc<M>(A0, q, Mr, lane);
+      tile_from_acc<M>(q, A0);
     }
     Acc<M> A;
     acc_from_tile<M>(A, q);
@@ -643,8 +654,10 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
       acc_zero<M>(A);
       rmul_acc<M>(A, q, smem, lane);
       tile_from_acc<M>(q, A);
-      Tile<M> qs = q;
-      store(qs, Q);
+      if (apply_rinv == 1) {  // 2: deferred normalisation -- Q stays un-normalised in memory, the next phase B applies rho^-1
+        Tile<M> qs = q;
+        store(qs, Q);
+      }
     }
     for (int s = 0; s < nshift; ++s) {
       Tile<M> pn, xn;
@@ -2389,14 +2402,18 @@ __global__ void __launch_bounds__(256) k_gram_mfma8(int64_t rows, const double2*
 // Phase B at m = 8: Q += T * negalpha through the m = 8 product tile, then the new 16 x 8 tile is re-read from a per-wave
 // LDS buffer in (row, column) ownership for the folded Gram product.
 __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
-                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials) {
+                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials,
+                                                 const double2* __restrict__ rinv) {
   constexpr int M = 8, NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row
+  constexpr int MDs = (MatLds<M>::DOUBLES + 1) & ~1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ml = smem;
-  double* scratch = smem + ((MatLds<M>::DOUBLES + 1) & ~1);  // max(NW*16*TLD, NW*8*64) doubles
+  double* Mr = smem + MDs;                        // rinv, when given (see k_phaseB)
+  double* scratch = smem + MDs * (rinv ? 2 : 1);  // max(NW*16*TLD, NW*8*64) doubles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   stage_matrix<M>(Ml, negalpha, tid, 256);
+  if (rinv) stage_matrix<M>(Mr, rinv, tid, 256);
   __syncthreads();
   const int r = lane & 15, kq = lane >> 4;
   double* tw = scratch + wave * 16 * TLD;
@@ -2409,6 +2426,12 @@ __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, doub
     Tile<M> t, q;
     tile_load<M>(t, T, row, kq, ok);
     tile_load<M>(q, Q, row, kq, ok);
+    if (rinv) {
+      Acc<M> A0;
+      acc_zero<M>(A0);
+      rmul_acc<M>(A0, q, Mr, lane);
+      tile_from_acc<M>(q, A0);
+    }
     Acc<M> A;
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
@@ -2442,20 +2465,20 @@ int phaseC_max_shifts(int m, bool applies_rinv) {
 }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks, GramFold gf) {
+                  double2* partials, int max_blocks, GramFold gf, const double2* rinv) {
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
   if (m == 8) {
-    const size_t lds = sizeof(double) * (((MatLds<8>::DOUBLES + 1) & ~1) + 4 * 8 * 64);  // RED 2048 >= TRN 4*16*18
-    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials);
+    const size_t lds = sizeof(double) * (((MatLds<8>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 8 * 64);  // RED 2048 >= TRN 4*16*18
+    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials, rinv);
   } else if (m == 16) {
     constexpr int M = 16;
-    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf);
+    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv);
   } else {
     constexpr int M = 32;
-    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) + 4 * 16 * 66);  // TRN 4224 >= RED 2048: 50 KB, 3 blocks per CU
+    const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 16 * 66);  // TRN 4224 >= RED 2048: 50 KB, 3 blocks per CU
     allow_lds(k_phaseB<M>, lds);
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv);
   }
   return grid;
 }

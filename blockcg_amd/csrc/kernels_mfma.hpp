@@ -20,10 +20,11 @@ struct GramFold {
   unsigned* tickets = nullptr;
 };
 
-// Phase B: Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
+// Phase B: [Q <- Q * rinv if rinv] ; Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks, GramFold fold = GramFold());
-// Phase C: if apply_rinv Q <- Q*mats[0]; for k < nshift: X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + Q.
+                  double2* partials, int max_blocks, GramFold fold = GramFold(), const double2* rinv = nullptr);
+// Phase C: q = Q*mats[0] if apply_rinv (1: stored back to Q; 2: used, not stored); for k < nshift:
+// X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + q.
 void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
                    const double2* mats, int apply_rinv, int max_blocks);
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,

@@ -588,3 +588,34 @@ def test_fused_true_residual_check(bc, orc, monkeypatch):
     assert 1e-6 < want.max() < 1.0
     assert rel_err(got["1"][0], want) < 1e-11
     assert rel_err(got["0"][0], want) < 1e-11
+
+
+@pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
+def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypatch):
+    """Phase C keeps Q rho^-1 in registers and leaves the un-normalised Q in memory; the next phase B applies the same
+    rho^-1 with the same kernel arithmetic (blockcg_capi.hip: lazy_q_width): the iterates must equal, bit for bit, those of
+    the form that stores Q rho^-1 and reads it back (BCG_LAZY_Q=0), and match the oracle."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    shifts, iters, mass = [0.0, 1e-3, 0.1], 6, 0.2
+    outs = []
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("BCG_LAZY_Q", lazy)
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, seed=51)
+        B = bc.block_fermion_field(ctx, m).setRandom(seed=52)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        info = bc.SBCGrQ(X, B, D, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters, return_info=True)
+        outs.append(([x.download() for x in X], info["trace"], ctx.profile()))
+    for s in range(len(shifts)):
+        assert np.array_equal(outs[0][0][s], outs[1][0][s])
+    for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+        assert np.array_equal(outs[0][1][key], outs[1][1][key]), key
+    # one field pass less in phase C: (1 + 4 S) s against (2 + 4 S) s of algorithmic bytes per launch
+    S = len(shifts)
+    assert outs[0][2]["phaseC"]["bytes"] * (2 + 4 * S) == pytest.approx(outs[1][2]["phaseC"]["bytes"] * (1 + 4 * S), rel=1e-9)
+    U = orc.fill_gauge(dims, 51)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 52)
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters)
+    for s in range(len(shifts)):
+        assert rel_err(outs[0][0][s], o["X"][s]) < 1e-10
