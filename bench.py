@@ -347,7 +347,12 @@ def main():
                                       "(64^3x128 per GPU, capacity ring 32)" if default_shape else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
             "iterations_per_sec": its,
+            # bytes_alg of SURVEY.md section 8d, V[(14 + 4(S-1)) 48 m + 2 g]: the metric's definition.  The iteration itself
+            # moves one field pass less since round 3 (Q rho^-1 is not stored): see bytes_moved_minimum
             "hbm_GBps_algorithmic": hbm_gbps, "hbm_GBps_per_gpu": hbm_gbps / world,
+            "bytes_alg_per_iteration": bytes_iter_total,
+            "bytes_moved_minimum_per_iteration": sum(v.get("bytes", 0.0) for k, v in prof.items()
+                                                     if not k.startswith("stencil_form_")) / K * world,
             "hbm_roofline_frac_whole_iteration": hbm_gbps / world / HBM_PEAK_GBPS,
             "residual_after_timed_steps": residual,
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("stencil_form_")},

@@ -867,7 +867,7 @@ int rmul(bcg_context* c, bcg_field* y, const bcg_field* x, const CMat& M, double
 // rho^-1 (same kernel arithmetic, same order: bit-identical iterates) before subtracting T alpha.  One field pass less per
 // iteration: (1 + 4 S) s in phase C instead of (2 + 4 S) s.  BCG_LAZY_Q=0 switches it off.
 bool lazy_q_width(const bcg_context* c, int m) {
-  return c->lazy_q && fast_rows(c, m) && fast_rmul(c, m) && (m == 8 || m == 16);
+  return c->lazy_q && fast_rows(c, m) && fast_rmul(c, m) && (m == 8 || m == 16 || (m == 32 && c->lazy_q > 1));
 }
 
 // rinv_prev: the stored Q is the previous iteration's un-normalised block, to be multiplied by this first (nullptr: Q as it is)
@@ -1025,7 +1025,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
-  if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
