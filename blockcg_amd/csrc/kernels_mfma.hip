@@ -2623,6 +2623,14 @@ static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const
          (pl.hw.p0 / spw) * (pl.hw.p1 / 2) * (pl.hw.p2 / 2) == pl.grid / 8;
 }
 
+// The bundle sweep is paced only where it is free: whole-field launches of at least 256 steps per block.  Measured
+// (profiles/r03_pacing_ab_other_shapes.txt): at 64^4 (2048 steps) paced = unpaced in time with 20 % less fabric traffic; at
+// 32^4, m = 8 (64 steps) the paced plain hop takes 0.376 vs 0.360 ms; capacity-mode windows (15-30 slices) 22.3 vs 21.6 ms.
+// BCG_HOP_BUNDLE_SYNC < 0 forces pacing with window |value| everywhere (tests).
+static bool bundle_paced(int ntiles, int grid, const HopWindow& win) {
+  return win.ring == 0 && grid > 0 && ntiles / grid >= 256;
+}
+
 template <int M>
 static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, const double2* Ughost, const double2* in,
                        const double2* ghost, double2* out, HopMode mode, const double2* p, double c0, double2* partials,
@@ -2646,7 +2654,8 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
       return -1;
     constexpr int MC = hop4b_share_images(M) ? M : 16;  // (never launched for the other widths)
     HopWalk hwb = hw;
-    if (tune.sync.bundle_window > 0 && hw.sync) hwb.sync_window = tune.sync.bundle_window;
+    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(ntiles, grid, win)))
+      hwb.sync_window = tune.sync.bundle_window < 0 ? -tune.sync.bundle_window : tune.sync.bundle_window;
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
     constexpr int SPWc = 64 / MC;
@@ -2666,8 +2675,9 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   }
   // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
   if (bundle_ok(M, lat, tune, pl, cls, mode == HOP_PLAIN)) {
-    HopWalk hwb = hw;  // pacing of the bundle sweep: its own window (default none)
-    if (tune.sync.bundle_window > 0 && hw.sync) hwb.sync_window = tune.sync.bundle_window;
+    HopWalk hwb = hw;  // pacing of the bundle sweep: its own window, long whole-field sweeps only (bundle_paced)
+    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(ntiles, grid, win)))
+      hwb.sync_window = tune.sync.bundle_window < 0 ? -tune.sync.bundle_window : tune.sync.bundle_window;
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
     constexpr int SPW = 64 / M;

@@ -41,7 +41,7 @@ struct HopSync {
   bool column_walk = true;       // use k_hop4c (scalar row pointers, column sweep) where the walk allows it
   int bundle_walk = 1;           // k_hop4b (2 x 2 column bundles sharing rows through LDS) for whole launches: 0 off, 1 at
                                  // m = 16 and 32 and for the plain hop at m = 8, 2 for every launch at m = 8 too
-  int bundle_window = 4;         // pacing window of k_hop4b (0 = unpaced).  Round 3, links by LDS-DMA: windows 4..12 take the
+  int bundle_window = 4;         // pacing window of k_hop4b (0 = unpaced; < 0: |value|, also where bundle_paced() would not pace).  Round 3, links by LDS-DMA: windows 4..12 take the
                                  // same time as the unpaced sweep (10.50 vs 10.46 ms, 12.00 vs 12.06 ms at 64^4) and move
                                  // 20 % fewer bytes past the L2 (45.7 vs 57.2 GB, 59.0 vs 72.0 GB); window 3 costs 2 %
 };

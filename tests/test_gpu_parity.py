@@ -527,7 +527,7 @@ def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, bundle, mon
     monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
     monkeypatch.setenv("BCG_HOP_SYNC", sync)
     monkeypatch.setenv("BCG_HOP_BUNDLE", bundle)
-    monkeypatch.setenv("BCG_HOP_BUNDLE_SYNC", sync)
+    monkeypatch.setenv("BCG_HOP_BUNDLE_SYNC", sync if sync == "0" else "-" + sync)  # < 0: pace short sweeps too
     V = int(np.prod(dims))
     U = orc.fill_gauge(dims, 71)
     Bh = orc.fill_field(m, V, 72)

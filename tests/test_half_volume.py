@@ -117,7 +117,7 @@ def test_checkerboard_bundle_sweep_matches_generic_and_oracle(orc, m, dims, patc
     import blockcg_amd as bc
     monkeypatch.setenv("BCG_HOP_PATCH", patch)
     monkeypatch.setenv("BCG_HOP_BLOCKS", "32")
-    monkeypatch.setenv("BCG_HOP_BUNDLE_SYNC", sync)
+    monkeypatch.setenv("BCG_HOP_BUNDLE_SYNC", sync if sync == "0" else "-" + sync)  # < 0: pace short sweeps too
     mass = 0.3
     shifts, iters = [0.0, 0.05], 4
     V = int(np.prod(dims))
