@@ -57,6 +57,7 @@ SIGNATURES = {
     "bcg_field_width": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_upload": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
     "bcg_field_download": (ctypes.c_int, [ctypes.c_void_p, c_dbl_p]),
+    "bcg_sbcgrq_device_bytes_half": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_size_p]),
     "bcg_field_create_half": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_field_parity": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_sites": (ctypes.c_int64, [ctypes.c_void_p]),

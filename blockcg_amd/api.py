@@ -104,6 +104,11 @@ class Context:
         self.check(self.lib.bcg_sbcgrq_device_bytes(self.h, m, n_shifts, 1 if consume_B else 0, ctypes.byref(n)))
         return n.value
 
+    def sbcgrq_device_bytes_half(self, m, n_shifts, consume_B=False):
+        n = ctypes.c_size_t()
+        self.check(self.lib.bcg_sbcgrq_device_bytes_half(self.h, m, n_shifts, 1 if consume_B else 0, ctypes.byref(n)))
+        return n.value
+
     def halo_buffers(self):
         s = ctypes.c_void_p()
         r = ctypes.c_void_p()

@@ -1232,6 +1232,19 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
   return BCG_OK;
 }
 
+// The same plan for ONE half-volume solve (bcg_field_create_half: every work field holds V/2 sites; links stay full)
+int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int consume_B, size_t* bytes_out) {
+  DeviceScope on_device(c);
+  if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
+  if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
+  const size_t half = static_cast<size_t>(c->lat.V / 2) * 3 * m * sizeof(double2);
+  size_t total = half * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1) + 1);  // X_s, P_s, Q, T (+ B), tmp
+  total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                  // links
+  total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
+  *bytes_out = total;
+  return BCG_OK;
+}
+
 // ---- fields ------------------------------------------------------------------------------------
 namespace {
 // parity -1: all local sites; 0 / 1: the parity-compact half (kernels_generic.hip, "Half-volume fields")

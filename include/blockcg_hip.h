@@ -129,6 +129,8 @@ int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
 /* Device memory one SBCGrQ solve of width m with n_shifts shifts occupies on this rank in the current mode: X_s, P_s,
  * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
+/* ... and one HALF-VOLUME solve (bcg_field_create_half below: all work fields hold V/2 sites, links stay full-volume) */
+int bcg_sbcgrq_device_bytes_half(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
 
 /* ---- fields: block_fermion_field<N_rhs> (inc/fields.hpp:25-147) --------------------------- */
 int bcg_field_create(bcg_context* ctx, int m, bcg_field** f);          /* explicit ctor :35 (contents undefined) */
