@@ -159,6 +159,19 @@ def launch_ranks(args, argv):
     print(lines[-1], flush=True)
 
 
+def apply_config(args, world):
+    """--config 4: the declared stand-in shape of BASELINE configs[4] (m = 32, 8 shifts; 128^4 at that width needs 8 TB): the
+    largest volume that fits 288 GB per GPU, 64^3 x 32 sites (19 fields of 12.9 GB + links = 250 GB), i.e. 128^3 x 32 on 8 GPUs.
+    --config 2 / 3 are the defaults at N = 1 / N > 1 and change nothing."""
+    if args.config == 4:
+        args.m, args.shifts = 32, 8
+        if args.local_dims is None:
+            args.local_dims = [64, 64, 64, 32]
+        if args.capacity is None:
+            args.capacity = 32 if world > 1 else 0  # ring = L3: no memory saved, but the chunked exchanges overlap
+    return args
+
+
 def resolve_shape(world, local_dims, capacity):
     """(sites per GPU, capacity ring, on-the-headline-ladder?) for a world size: the defaults documented at the top."""
     ladder = world > 1 and local_dims is None
@@ -195,12 +208,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.config == 4:  # declared stand-in shape of configs[4] (see --config)
-        args.m, args.shifts = 32, 8
-        if args.local_dims is None:
-            args.local_dims = [64, 64, 64, 32]
-        if args.capacity is None:
-            args.capacity = 32 if world > 1 else 0  # ring = L3: no memory saved, but the chunked exchanges overlap
+    apply_config(args, world)
     if os.environ.get("BCG_BENCH_TEST_HANG"):  # tests/test_bench_launcher.py: a rank that never finishes
         time.sleep(3600)
     default_shape = args.local_dims is None and args.capacity is None

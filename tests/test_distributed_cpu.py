@@ -63,3 +63,25 @@ def test_bench_selects_the_headline_ladder():
         assert g == grid and [l * x for l, x in zip(local, g)] == gdims
         assert sorted(tuple(coords_of(r, g)) for r in range(n)) == sorted(set(tuple(coords_of(r, g)) for r in range(n)))
     assert bench.resolve_shape(2, [16, 16, 16, 16], None) == ([16, 16, 16, 16], 0, False)  # explicit shape: no capacity mode
+
+
+def test_bench_config_4_is_the_declared_wide_block_shape():
+    """bench.py --config 4: BASELINE configs[4]'s width and shift count on the largest volume that fits a GPU."""
+    import argparse
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from blockcg_amd.comm import grid_for
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world, cap in ((1, 0), (8, 32)):
+        a = bench.apply_config(argparse.Namespace(config=4, m=16, shifts=4, local_dims=None, capacity=None), world)
+        assert (a.m, a.shifts, a.local_dims, a.capacity) == (32, 8, [64, 64, 64, 32], cap)
+        local, capacity, ladder = bench.resolve_shape(world, a.local_dims, a.capacity)
+        assert local == [64, 64, 64, 32] and capacity == cap and not ladder
+        # 19 fields (X_s, P_s, Q = B, T, tmp) of 64^3 x 32 sites x 1536 B + links: under 288 GB
+        assert (19 * 64 ** 3 * 32 * 1536 + 64 ** 3 * 32 * 576) < 260e9
+    assert grid_for(8, 4, keep_last=True) == [2, 2, 2, 1]
+    b = bench.apply_config(argparse.Namespace(config=None, m=16, shifts=4, local_dims=None, capacity=None), 1)
+    assert (b.m, b.shifts, b.local_dims) == (16, 4, None)
