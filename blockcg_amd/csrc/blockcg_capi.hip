@@ -871,9 +871,12 @@ bool lazy_q_width(const bcg_context* c, int m) {
 }
 
 // rinv_prev: the stored Q is the previous iteration's un-normalised block, to be multiplied by this first (nullptr: Q as it is)
-int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha, CMat& G2, const CMat* rinv_prev = nullptr) {
+// Qout (fused kernel only): the new Q is written there and Q keeps the old block (pair_shifts below)
+int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha, CMat& G2, const CMat* rinv_prev = nullptr,
+            bcg_field* Qout = nullptr) {
   const int m = Q->m;
   if (!fast_rows(c, m)) {
+    if (Qout) BCG_FAIL(c, BCG_ERR_INVALID, "phase B: a separate output needs the fused kernel");
     BCG_TRY(rmul(c, Q, T, -alpha, 0.0, bcg::RMUL_ADD, "block_axpy"));
     return gram(c, Q, Q, G2);
   }
@@ -886,7 +889,7 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
     ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
     nb = bcg::launch_phaseB(c->stream, m, rows_of(Q), Q->d, T->d, Md, c->partials, c->row_blocks_B,
                             bcg::GramFold{c->dev_gram, c->fold_tickets},
-                            rinv_prev ? Md + static_cast<size_t>(m) * m : nullptr);
+                            rinv_prev ? Md + static_cast<size_t>(m) * m : nullptr, Qout ? Qout->d : nullptr);
   }
   BCG_TRY(check_launch(c, "phaseB"));
   return finish_gram(c, m, nb, G2, true, /*folded=*/true);
@@ -932,6 +935,54 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     BCG_TRY(check_launch(c, "phaseC"));
   }
   return BCG_OK;
+}
+
+// Two iterations of the shifted systems in one pass (SBCGrQ below; kernels_mfma.hip: k_phaseC_pair).  The reference
+// updates X_s and P_s of every active shift in every iteration (:175, :177), but only P_0 is read by the rest of the
+// iteration (:135).  So an iteration k that is certain to be followed by another one updates shift 0 only and keeps its
+// un-normalised residual block: phase B of iteration k+1 writes the new block into a second buffer, and phase C of k+1
+// applies both iterations' updates to the shifts >= 1 with X_s, P_s read and written once.  Same kernel arithmetic on the
+// same values: bit-identical fields after every even number of iterations (and after an odd one, whose last iteration
+// is not deferred).  Per pair of iterations phase C moves (5 + 6 + 4 (S-1)) s instead of 2 (1 + 4 S) s; one more field
+// of memory, so not in capacity mode.  BCG_PAIR_SHIFTS=0 switches it off.
+bool pair_shifts_width(const bcg_context* c, int m, int n_shifts) {
+  return c->pair_shifts && lazy_q_width(c, m) && (m == 8 || m == 16) && n_shifts >= 2 && !capacity_path(c, m) &&
+         bcg::phaseC_pair_fits(m, 1, n_shifts - 1, 0);
+}
+
+// Entries: shift 0 with iteration k+1's coefficients (A0, B0), then the shifts active in both iterations, then those
+// active in iteration k only.  A1/B1: iteration k's coefficients, A2/B2: iteration k+1's, both indexed by shift.
+int phase_C_pair(bcg_context* c, bcg_field* Qold, const CMat& rinv_old, bcg_field* Qnew, const CMat& rho_new,
+                 bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_old, int n_active_new,
+                 const std::vector<CMat>& A1, const std::vector<CMat>& B1, const std::vector<CMat>& A2,
+                 const std::vector<CMat>& B2, CMat* rinv_out) {
+  const int m = Qold->m;
+  const CMat rinv_new = bcg::upper_triangular_inverse(rho_new);
+  *rinv_out = rinv_new;
+  std::vector<const CMat*> mats{&rinv_old, &rinv_new, &A0, &B0};
+  double2* Xp[8];
+  double2* Pp[8];
+  int n = 0;
+  Xp[n] = X[0]->d;
+  Pp[n++] = P[0]->d;
+  const int n2 = n_active_new - 1, n1 = n_active_old - n_active_new;
+  for (int s = 1; s < n_active_old; ++s) {
+    mats.push_back(&A1[s]);
+    mats.push_back(&B1[s]);
+    if (s < n_active_new) {
+      mats.push_back(&A2[s]);
+      mats.push_back(&B2[s]);
+    }
+    Xp[n] = X[s]->d;
+    Pp[n++] = P[s]->d;
+  }
+  const double2* Md;
+  BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
+  {
+    ProfScope ps(c, "phaseC_pair", alg_bytes(c, m, 2 + 4 * n));
+    bcg::launch_phaseC_pair(c->stream, m, rows_of(Qold), Qold->d, Qnew->d, Xp, Pp, 1, n2, n1, Md, c->row_blocks_C);
+  }
+  return check_launch(c, "phaseC_pair");
 }
 
 // thinQR (inc/fields.hpp:140-146)
@@ -1026,6 +1077,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
+  if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
@@ -1223,6 +1275,7 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
   const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
   size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
+  if (pair_shifts_width(c, m, n_shifts)) total += field;                                  // second residual buffer
   total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
   total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
@@ -1239,6 +1292,7 @@ int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int 
   if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
   const size_t half = static_cast<size_t>(c->lat.V / 2) * 3 * m * sizeof(double2);
   size_t total = half * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1) + 1);  // X_s, P_s, Q, T (+ B), tmp
+  if (pair_shifts_width(c, m, n_shifts)) total += half;                                     // second residual buffer
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                  // links
   total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
   *bytes_out = total;
@@ -1775,6 +1829,12 @@ struct bcg_sbcgrq_state {
   int iter = 0;
   CMat q_rinv;          // deferred normalisation (lazy_q_width): the stored Q times this is the reference's Q
   bool q_lazy = false;
+  // pair_shifts_width: the updates of the shifts >= 1 of the previous iteration wait for this one
+  bcg_field* Qspare = nullptr;           // second residual buffer; after a paired iteration Q and Qspare have swapped
+  bool pending = false;
+  int pend_active = 0;                   // n_active of the deferred iteration
+  std::vector<CMat> pend_A, pend_B;      // its coefficients, by shift
+  CMat pend_rinv;                        // its rho^-1
 };
 
 namespace {
@@ -1782,6 +1842,8 @@ namespace {
 void sbcgrq_release(bcg_sbcgrq_state* st) {
   if (st->T) bcg_field_destroy(st->T);
   if (st->Q && st->Q != st->B) bcg_field_destroy(st->Q);
+  if (st->Qspare && st->Qspare != st->B) bcg_field_destroy(st->Qspare);
+  st->Qspare = nullptr;
   for (bcg_field* p : st->P)
     if (p) bcg_field_destroy(p);
   st->T = st->Q = nullptr;
@@ -1789,7 +1851,8 @@ void sbcgrq_release(bcg_sbcgrq_state* st) {
 }
 
 // One pass of the loop body, inc/block_solvers.hpp:133-182.
-int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
+// more_follow: the caller will run at least one more iteration if this one leaves the residual above eps
+int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_follow) {
   bcg_context* c = st->c;
   const int m = st->m, n_shifts = st->n_shifts;
   const std::vector<double>& sigma = st->sigma;
@@ -1803,7 +1866,12 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
   const CMat alpha_delta = st->alpha * st->delta;        // :145 uses delta of the previous iteration
   // Q -= T alpha ; Gram matrix of the new Q                                  :148, :152
   CMat G2;
-  BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
+  if (st->pending) {  // the old block is still needed by this iteration's phase C: the new one goes to the other buffer
+    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, &st->q_rinv, st->Qspare));           // global reduction #2
+    std::swap(st->Q, st->Qspare);
+  } else {
+    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
+  }
   st->rho_old = st->rho;                                 // :150
   if (!G2.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not finite");
   if (!bcg::cholesky_upper(G2, st->rho)) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not positive definite");
@@ -1834,6 +1902,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
   const CMat rho_dag = st->rho.adjoint();
   std::vector<CMat> Acoef(1, alpha_delta), Bcoef(1, rho_dag);
   std::vector<bcg_field*> Xa(1, st->X[0]), Pa(1, st->P[0]);
+  std::vector<CMat> A_by_shift(n_shifts), B_by_shift(n_shifts);
   const int n_active = st->n_unconverged;
   for (int s = n_active - 1; s > 0; --s) {  // :161
     const CMat beta_s_inv = Identity + (sigma[s] - sigma[0]) * st->alpha +
@@ -1844,6 +1913,8 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
     const double residual_shift = max_ratio((st->rho * st->alpha_inv * st->alpha_s[s]).row_norms(), st->b_norm);  // :169-172
     Acoef.push_back(st->alpha_s[s]);                                                                     // :175
     Bcoef.push_back(st->beta_s[s] * rho_dag);                                                            // :177
+    A_by_shift[s] = Acoef.back();
+    B_by_shift[s] = Bcoef.back();
     Xa.push_back(st->X[s]);
     Pa.push_back(st->P[s]);
     if (tm) {
@@ -1854,8 +1925,23 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace) {
     if (residual_shift < st->eps_shifts) --st->n_unconverged;  // :179-181
   }
   const bool lazy = lazy_q_width(c, m);
-  BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
-                  lazy ? &st->q_rinv : nullptr));
+  if (st->pending) {
+    // Q = this iteration's un-normalised block, Qspare = the deferred iteration's (phase B above swapped them)
+    BCG_TRY(phase_C_pair(c, st->Qspare, st->pend_rinv, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag,
+                         st->pend_active, n_active, st->pend_A, st->pend_B, A_by_shift, B_by_shift, &st->q_rinv));
+    st->pending = false;
+  } else if (st->Qspare && n_active >= 2 && more_follow && st->residual > st->eps) {
+    // another iteration is certain: shift 0 now, the others together with the next iteration's updates
+    BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), 1, Acoef, Bcoef, &st->q_rinv));
+    st->pending = true;
+    st->pend_active = n_active;
+    st->pend_A = A_by_shift;
+    st->pend_B = B_by_shift;
+    st->pend_rinv = st->q_rinv;
+  } else {
+    BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
+                    lazy ? &st->q_rinv : nullptr));
+  }
   st->q_lazy = lazy;  // from now on the stored Q is un-normalised: Q_true = Q q_rinv
   if (tracing) trace->recorded += 1;
   return BCG_OK;
@@ -1920,6 +2006,11 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
 #undef BEGIN_TRY
   st->alpha_s.assign(n_shifts, Identity);  // :122
   st->beta_s.assign(n_shifts, Identity);   // :123
+  if (pair_shifts_width(c, m, n_shifts) && create_like(c, B, &st->Qspare) != BCG_OK) {
+    st->Qspare = nullptr;  // no room for the second residual buffer: every iteration updates every shift
+    (void)hipGetLastError();
+    c->err.clear();
+  }
   st->iter = 0;                            // :126
   st->b_norm = st->delta.row_norms();      // :130
   st->residual = 1.0;                      // :131
@@ -1933,7 +2024,7 @@ int bcg_sbcgrq_iterate(bcg_sbcgrq_state* st, int max_new_iterations, int* iterat
   if (!st) return BCG_ERR_INVALID;
   int done = 0;
   while (st->residual > st->eps && done < max_new_iterations) {  // :132
-    BCG_TRY(sbcgrq_iteration(st, trace));
+    BCG_TRY(sbcgrq_iteration(st, trace, done + 1 < max_new_iterations));
     ++done;
   }
   BCG_TRY(stream_sync(st->c));

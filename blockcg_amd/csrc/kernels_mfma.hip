@@ -493,9 +493,10 @@ __device__ __forceinline__ void gram_fold(const GramFold& gf, double2* __restric
 template <int M>
 // rinv != nullptr (deferred normalisation, see phase_B in blockcg_capi.hip): the stored Q is the previous iteration's
 // un-normalised block; it is multiplied by rinv = rho_prev^-1 first -- the arithmetic phase C used to do before storing it.
-__global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
+// Qout: where the new Q goes (== Q: in place; another buffer when the old block must survive, see k_phaseC_pair).
+__global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, const double2* __restrict__ T,
                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials,
-                                                GramFold gf, const double2* __restrict__ rinv) {
+                                                GramFold gf, const double2* __restrict__ rinv, double2* Qout) {
   constexpr int NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row (M*16 + 16 bytes)
   constexpr int JB = M / 16;
@@ -571,12 +572,12 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, double2* __restric
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
     tile_from_acc<M>(q, A);
-    if (!LINB) tile_store<M>(q, Q, row, kq, ok);
+    if (!LINB) tile_store<M>(q, Qout, row, kq, ok);
     // transpose the new tile through LDS: write (r, j = 4s+kq), read (row = 4g + (l>>4), j = l&15 + 16 jb)
 #pragma unroll
     for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = q.v[s];
     // same wave wrote and reads: no barrier needed, only LDS ordering (ds ops of one wave are in order)
-    double2* const qtile = Q + tile * (16 * M);
+    double2* const qtile = Qout + tile * (16 * M);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       double2 a[JB];
@@ -685,6 +686,87 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
           load(p, sp.P[s + 1]);
           load(x, sp.X[s + 1]);
         }
+      }
+    }
+  }
+}
+
+// Phase C of TWO consecutive iterations k, k+1 in one pass over the fields of the shifted systems (m = 8, 16).
+// Only P_0 feeds the operator, so the updates of shift s >= 1 of iteration k can wait for iteration k+1 as long as the
+// un-normalised residual block of iteration k is kept (Qold; phase B of k+1 wrote its result to Qnew instead of in place):
+//   q_old = Qold rinv_old ; q_new = Qnew rinv_new                      (neither is stored: deferred normalisation)
+//   entry e < n0          (shift 0, iteration k+1 only):  X += P A ; P <- P B + q_new
+//   n0 <= e < n0 + n2     (both iterations):              X += P A1 ; P <- P B1 + q_old ; X += P A2 ; P <- P B2 + q_new
+//   the n1 entries after  (left the active set at k+1):   X += P A1 ; P <- P B1 + q_old
+// with the intermediate X, P in registers.  Every product is the instruction sequence of k_phaseC on the same fp64
+// values (a store and a load between the two steps would not change them), so the fields are bit-identical to two
+// k_phaseC passes; X_s and P_s are read and written once instead of twice.
+// mats: [rinv_old, rinv_new, then per entry A, B (one step) or A1, B1, A2, B2 (two steps)], consecutive.
+// NW = 12: one block per CU, 3 waves per SIMD (168 registers: two residual tiles, the entry's and the next entry's
+// P and X tiles, two accumulators), whatever the matrices take of the CU's LDS (up to 32 of them at 8 shifts).
+template <int M, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_phaseC_pair(int64_t rows, const double2* __restrict__ Qold, const double2* __restrict__ Qnew, ShiftPtrs sp, int n0, int n2,
+              int n1, const double2* __restrict__ mats) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nent = n0 + n2 + n1;
+  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
+  for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k) * M * M, tid, NW * 64);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t ntiles = (rows + 15) / 16;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = row < rows;
+    Tile<M> qo, qn, p, x;
+    tile_load<M>(qo, Qold, row, kq, ok);
+    tile_load<M>(qn, Qnew, row, kq, ok);
+    if (nent > 0) {
+      tile_load<M>(p, sp.P[0], row, kq, ok);
+      tile_load<M>(x, sp.X[0], row, kq, ok);
+    }
+    {
+      Acc<M> A;
+      acc_zero<M>(A);
+      rmul_acc<M>(A, qo, smem, lane);
+      tile_from_acc<M>(qo, A);
+      acc_zero<M>(A);
+      rmul_acc<M>(A, qn, smem + MD, lane);
+      tile_from_acc<M>(qn, A);
+    }
+    const double* mat = smem + 2 * MD;
+    for (int e = 0; e < nent; ++e) {
+      Tile<M> pn, xn;
+      if (e + 1 < nent) {  // the next entry's tiles are in flight while this one is multiplied
+        tile_load<M>(pn, sp.P[e + 1], row, kq, ok);
+        tile_load<M>(xn, sp.X[e + 1], row, kq, ok);
+      }
+      const bool first_step = e >= n0, second_step = e < n0 + n2;  // wave-uniform
+      if (first_step) {
+        Acc<M> AX, AP;
+        acc_from_tile<M>(AX, x);
+        acc_from_tile<M>(AP, qo);
+        rmul_acc2<M>(AX, mat, AP, mat + MD, p, lane);
+        tile_from_acc<M>(x, AX);
+        tile_from_acc<M>(p, AP);
+        mat += 2 * MD;
+      }
+      if (second_step) {
+        Acc<M> AX, AP;
+        acc_from_tile<M>(AX, x);
+        acc_from_tile<M>(AP, qn);
+        rmul_acc2<M>(AX, mat, AP, mat + MD, p, lane);
+        tile_from_acc<M>(x, AX);
+        tile_from_acc<M>(p, AP);
+        mat += 2 * MD;
+      }
+      tile_store<M>(x, sp.X[e], row, kq, ok);
+      tile_store<M>(p, sp.P[e], row, kq, ok);
+      if (e + 1 < nent) {
+        p = pn;
+        x = xn;
       }
     }
   }
@@ -2401,9 +2483,9 @@ __global__ void __launch_bounds__(256) k_gram_mfma8(int64_t rows, const double2*
 
 // Phase B at m = 8: Q += T * negalpha through the m = 8 product tile, then the new 16 x 8 tile is re-read from a per-wave
 // LDS buffer in (row, column) ownership for the folded Gram product.
-__global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, double2* __restrict__ Q, const double2* __restrict__ T,
+__global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, const double2* Q, const double2* __restrict__ T,
                                                  const double2* __restrict__ negalpha, double2* __restrict__ partials,
-                                                 const double2* __restrict__ rinv) {
+                                                 const double2* __restrict__ rinv, double2* Qout) {
   constexpr int M = 8, NW = 4;
   constexpr int TLD = M * 2 + 2;  // doubles per transposition row
   constexpr int MDs = (MatLds<M>::DOUBLES + 1) & ~1;
@@ -2436,7 +2518,7 @@ __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, doub
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
     tile_from_acc<M>(q, A);
-    tile_store<M>(q, Q, row, kq, ok);
+    tile_store<M>(q, Qout, row, kq, ok);
 #pragma unroll
     for (int sx = 0; sx < M / 4; ++sx) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * sx + kq)) = ok ? q.v[sx] : make_double2(0.0, 0.0);
     // same wave wrote and reads (LDS operations of one wave are in order): rows 8g .. 8g+7, one per 8 lanes
@@ -2465,20 +2547,21 @@ int phaseC_max_shifts(int m, bool applies_rinv) {
 }
 
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks, GramFold gf, const double2* rinv) {
+                  double2* partials, int max_blocks, GramFold gf, const double2* rinv, double2* Qout) {
+  if (!Qout) Qout = Q;
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks);
   if (m == 8) {
     const size_t lds = sizeof(double) * (((MatLds<8>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 8 * 64);  // RED 2048 >= TRN 4*16*18
-    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials, rinv);
+    hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials, rinv, Qout);
   } else if (m == 16) {
     constexpr int M = 16;
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv, Qout);
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 16 * 66);  // TRN 4224 >= RED 2048: 50 KB, 3 blocks per CU
     allow_lds(k_phaseB<M>, lds);
-    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv);
+    hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv, Qout);
   }
   return grid;
 }
@@ -2525,6 +2608,32 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
       hipLaunchKernelGGL((k_phaseC<M, false>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
     }
   }
+}
+
+bool phaseC_pair_fits(int m, int n0, int n2, int n1) {
+  if (m != 8 && m != 16) return false;
+  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
+  const size_t md = m == 8 ? ((MatLds<8>::DOUBLES + 1) & ~1) : ((MatLds<16>::DOUBLES + 1) & ~1);
+  return n0 + n2 + n1 <= 8 && sizeof(double) * md * nmat <= 150 * 1024;
+}
+
+void launch_phaseC_pair(hipStream_t s, int m, int64_t rows, const double2* Qold, const double2* Qnew, double2* const* X,
+                        double2* const* P, int n0, int n2, int n1, const double2* mats, int max_blocks) {
+  ShiftPtrs sp{};
+  for (int k = 0; k < n0 + n2 + n1 && k < 8; ++k) {
+    sp.X[k] = X[k];
+    sp.P[k] = P[k];
+  }
+  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
+#define BCG_PAIR(MM)                                                                                              \
+  {                                                                                                               \
+    const size_t lds = sizeof(double) * ((MatLds<MM>::DOUBLES + 1) & ~1) * nmat;                                  \
+    const int grid = grid_tiles((rows + 15) / 16, 12, max_blocks / 4 > 0 ? max_blocks / 4 : 1);                   \
+    allow_lds(k_phaseC_pair<MM, 12>, lds);                                                                        \
+    hipLaunchKernelGGL((k_phaseC_pair<MM, 12>), dim3(grid), dim3(768), lds, s, rows, Qold, Qnew, sp, n0, n2, n1, mats);  \
+  }
+  if (m == 8) BCG_PAIR(8) else BCG_PAIR(16)
+#undef BCG_PAIR
 }
 
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,

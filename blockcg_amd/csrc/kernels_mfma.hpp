@@ -22,11 +22,18 @@ struct GramFold {
 
 // Phase B: [Q <- Q * rinv if rinv] ; Q += T * negalpha ; partials of (new Q)^dagger (new Q).  Returns blocks used.
 int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2* T, const double2* negalpha,
-                  double2* partials, int max_blocks, GramFold fold = GramFold(), const double2* rinv = nullptr);
+                  double2* partials, int max_blocks, GramFold fold = GramFold(), const double2* rinv = nullptr,
+                  double2* Qout = nullptr);  // Qout: the new Q goes there and Q is left as it was (nullptr: in place)
 // Phase C: q = Q*mats[0] if apply_rinv (1: stored back to Q; 2: used, not stored); for k < nshift:
 // X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + q.
 void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
                    const double2* mats, int apply_rinv, int max_blocks);
+// Phase C of two consecutive iterations for the shifts that do not feed the operator (kernels_mfma.hip: k_phaseC_pair).
+// Entries: n0 (0 or 1) with one step on q_new, then n2 with both steps, then n1 with one step on q_old.
+// mats = [rinv_old, rinv_new, per entry A, B or A1, B1, A2, B2].
+bool phaseC_pair_fits(int m, int n0, int n2, int n1);
+void launch_phaseC_pair(hipStream_t s, int m, int64_t rows, const double2* Qold, const double2* Qnew, double2* const* X,
+                        double2* const* P, int n0, int n2, int n1, const double2* mats, int max_blocks);
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,

@@ -596,6 +596,7 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
     rho^-1 with the same kernel arithmetic (blockcg_capi.hip: lazy_q_width): the iterates must equal, bit for bit, those of
     the form that stores Q rho^-1 and reads it back (BCG_LAZY_Q=0), and match the oracle."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    monkeypatch.setenv("BCG_PAIR_SHIFTS", "0")  # the paired updates build on this and have their own test below
     shifts, iters, mass = [0.0, 1e-3, 0.1], 6, 0.2
     outs = []
     for lazy in ("1", "0"):
@@ -619,3 +620,53 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
     o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters)
     for s in range(len(shifts)):
         assert rel_err(outs[0][0][s], o["X"][s]) < 1e-10
+
+
+@pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
+def test_paired_shift_updates_are_bit_identical(bc, orc, m, dims, monkeypatch):
+    """The shifts >= 1 are updated two iterations at a time (blockcg_capi.hip: pair_shifts_width, k_phaseC_pair).  After any
+    number of iterations -- even, odd, run in one call or in pieces, with shifts leaving the active set on the way -- X,
+    the coefficient trace and the iteration count must equal, bit for bit, those of the solver that updates every shift in
+    every iteration (BCG_PAIR_SHIFTS=0), and match the oracle."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    shifts, mass = [0.0, 1e-3, 0.1, 2.0], 0.2
+    U = orc.fill_gauge(dims, 61)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 62)
+
+    def run(pair, pieces, eps_shifts):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", pair)
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, eps_shifts)
+        for n in pieces:
+            st.iterate(n)
+        res = st.residual
+        st.end()
+        return [x.download() for x in X], res, ctx.profile()
+
+    for pieces, eps_shifts in (([6], 0.0), ([7], 0.0), ([2, 3, 1, 4], 0.0), ([1, 1, 1], 0.0), ([9], 3e-2), ([4, 5], 0.5)):
+        a, ra, pa = run("1", pieces, eps_shifts)
+        b, rb, pb = run("0", pieces, eps_shifts)
+        assert ra == rb
+        for s in range(len(shifts)):
+            assert np.array_equal(a[s], b[s]), (pieces, eps_shifts, s)
+        assert "phaseC_pair" not in pb
+        pairs = sum(n // 2 for n in pieces)
+        if eps_shifts == 0.0:
+            assert pa.get("phaseC_pair", {}).get("count", 0) == pairs, (pieces, pa.get("phaseC_pair"))
+            # a pair moves 5 + (2 + 4 S) field passes where two plain iterations move 2 (1 + 4 S)
+            S = len(shifts)
+            if pairs:
+                per_pass = pb["phaseC"]["bytes"] / (sum(pieces) * (1 + 4 * S))
+                moved = pa["phaseC_pair"]["bytes"] + pa.get("phaseC", {}).get("bytes", 0.0)
+                assert moved == pytest.approx(per_pass * (pairs * (5 + 2 + 4 * S) + (sum(pieces) - 2 * pairs) * (1 + 4 * S)), rel=1e-9)
+    # shifts did leave the active set in the runs with eps_shifts > 0 (otherwise those runs test nothing new)
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 3e-2, max_iterations=9, trace_limit=9)
+    visited = o["trace"]["residual_shift"][:, 1:] >= 0.0  # -1 = the shift was not updated in that iteration
+    assert visited[0].all() and not visited[-1].all()
+    a, _, _ = run("1", [9], 3e-2)
+    for s in range(len(shifts)):
+        assert rel_err(a[s], o["X"][s]) < 1e-10
