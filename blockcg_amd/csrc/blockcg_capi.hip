@@ -937,52 +937,77 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
   return BCG_OK;
 }
 
-// Two iterations of the shifted systems in one pass (SBCGrQ below; kernels_mfma.hip: k_phaseC_pair).  The reference
+// Several iterations of the shifted systems in one pass (SBCGrQ below; kernels_mfma.hip: k_phaseC_multi).  The reference
 // updates X_s and P_s of every active shift in every iteration (:175, :177), but only P_0 is read by the rest of the
-// iteration (:135).  So an iteration k that is certain to be followed by another one updates shift 0 only and keeps its
-// un-normalised residual block: phase B of iteration k+1 writes the new block into a second buffer, and phase C of k+1
-// applies both iterations' updates to the shifts >= 1 with X_s, P_s read and written once.  Same kernel arithmetic on the
-// same values: bit-identical fields after every even number of iterations (and after an odd one, whose last iteration
-// is not deferred).  Per pair of iterations phase C moves (5 + 6 + 4 (S-1)) s instead of 2 (1 + 4 S) s; one more field
-// of memory, so not in capacity mode.  BCG_PAIR_SHIFTS=0 switches it off.
-bool pair_shifts_width(const bcg_context* c, int m, int n_shifts) {
-  return c->pair_shifts && lazy_q_width(c, m) && (m == 8 || m == 16) && n_shifts >= 2 && !capacity_path(c, m) &&
-         bcg::phaseC_pair_fits(m, 1, n_shifts - 1, 0);
+// iteration (:135).  So an iteration that is certain to be followed by another one updates shift 0 only and keeps its
+// un-normalised residual block: phase B of the next iteration writes the new block into another buffer, and the phase C
+// that ends the group (the `depth`-th iteration, or the last one before the loop can stop) applies every deferred
+// iteration's updates and its own to the shifts >= 1 with X_s, P_s read and written once.  Same kernel arithmetic on the
+// same values in the same order: the fields the caller sees after any number of iterations are bit-identical.  Per group
+// of D iterations phase C moves (5 (D-1) + D + 4 S) s instead of D (1 + 4 S) s; D - 1 more fields of memory, so not in
+// capacity mode.  BCG_PAIR_SHIFTS=<depth> (0 or 1: off; default 4, the largest instantiated).  Measured at 64^4,
+// m = 16, 4 shifts: 67.0 ms per iteration without, 55.5-56.1 at depth 2, 54.3 at 3, 53.4-53.7 at 4 (profiles/r03_group_depth.txt).
+int pair_shifts_depth(const bcg_context* c, int m, int n_shifts) {
+  if (c->pair_shifts < 2 || !lazy_q_width(c, m) || !(m == 8 || m == 16) || n_shifts < 2 || capacity_path(c, m)) return 1;
+  int d = std::min(c->pair_shifts, 4);
+  while (d >= 2 && !bcg::phaseC_multi_fits(m, d, n_shifts)) --d;
+  return d;
 }
 
-// Entries: shift 0 with iteration k+1's coefficients (A0, B0), then the shifts active in both iterations, then those
-// active in iteration k only.  A1/B1: iteration k's coefficients, A2/B2: iteration k+1's, both indexed by shift.
-int phase_C_pair(bcg_context* c, bcg_field* Qold, const CMat& rinv_old, bcg_field* Qnew, const CMat& rho_new,
-                 bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_old, int n_active_new,
-                 const std::vector<CMat>& A1, const std::vector<CMat>& B1, const std::vector<CMat>& A2,
-                 const std::vector<CMat>& B2, CMat* rinv_out) {
-  const int m = Qold->m;
+// An iteration whose updates of the shifts >= 1 wait for a later phase C
+struct DeferredIteration {
+  bcg_field* Q = nullptr;        // its un-normalised residual block
+  CMat rinv;                     // its rho^-1
+  int n_active = 0;              // shifts 1 .. n_active-1 were to be updated (:161)
+  std::vector<CMat> A, B;        // their coefficients, by shift
+};
+
+// The deferred iterations' updates and the current one's (coefficients A0/B0 for shift 0, Anew/Bnew by shift for the rest)
+int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bcg_field* Qnew, const CMat& rho_new,
+                  bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_new,
+                  const std::vector<CMat>& Anew, const std::vector<CMat>& Bnew, CMat* rinv_out) {
+  const int m = Qnew->m, ns = static_cast<int>(pend.size()) + 1;
   const CMat rinv_new = bcg::upper_triangular_inverse(rho_new);
-  *rinv_out = rinv_new;
-  std::vector<const CMat*> mats{&rinv_old, &rinv_new, &A0, &B0};
+  std::vector<const CMat*> mats;
+  const double2* Qd[4];
+  for (int j = 0; j + 1 < ns; ++j) {
+    mats.push_back(&pend[j].rinv);
+    Qd[j] = pend[j].Q->d;
+  }
+  mats.push_back(&rinv_new);
+  Qd[ns - 1] = Qnew->d;
   double2* Xp[8];
   double2* Pp[8];
-  int n = 0;
+  int first[8], last[8], n = 0;
   Xp[n] = X[0]->d;
-  Pp[n++] = P[0]->d;
-  const int n2 = n_active_new - 1, n1 = n_active_old - n_active_new;
-  for (int s = 1; s < n_active_old; ++s) {
-    mats.push_back(&A1[s]);
-    mats.push_back(&B1[s]);
-    if (s < n_active_new) {
-      mats.push_back(&A2[s]);
-      mats.push_back(&B2[s]);
+  Pp[n] = P[0]->d;
+  first[n] = ns - 1;
+  last[n++] = ns;
+  mats.push_back(&A0);
+  mats.push_back(&B0);
+  for (int s = 1; s < pend[0].n_active; ++s) {  // the active set only shrinks: a shift takes a prefix of the steps
+    int steps = 0;
+    for (int j = 0; j < ns; ++j) {
+      const bool on = s < (j + 1 < ns ? pend[j].n_active : n_active_new);
+      if (!on) break;
+      mats.push_back(j + 1 < ns ? &pend[j].A[s] : &Anew[s]);
+      mats.push_back(j + 1 < ns ? &pend[j].B[s] : &Bnew[s]);
+      ++steps;
     }
     Xp[n] = X[s]->d;
-    Pp[n++] = P[s]->d;
+    Pp[n] = P[s]->d;
+    first[n] = 0;
+    last[n++] = steps;
   }
   const double2* Md;
   BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
   {
-    ProfScope ps(c, "phaseC_pair", alg_bytes(c, m, 2 + 4 * n));
-    bcg::launch_phaseC_pair(c->stream, m, rows_of(Qold), Qold->d, Qnew->d, Xp, Pp, 1, n2, n1, Md, c->row_blocks_C);
+    ProfScope ps(c, "phaseC_multi", alg_bytes(c, m, ns + 4 * n));
+    bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C);
   }
-  return check_launch(c, "phaseC_pair");
+  BCG_TRY(check_launch(c, "phaseC_multi"));
+  *rinv_out = rinv_new;
+  return BCG_OK;
 }
 
 // thinQR (inc/fields.hpp:140-146)
@@ -1077,7 +1102,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
-  if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
@@ -1275,7 +1300,7 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
   const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
   size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
-  if (pair_shifts_width(c, m, n_shifts)) total += field;                                  // second residual buffer
+  total += field * (pair_shifts_depth(c, m, n_shifts) - 1);                               // further residual buffers
   total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
   total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
@@ -1292,7 +1317,7 @@ int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int 
   if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
   const size_t half = static_cast<size_t>(c->lat.V / 2) * 3 * m * sizeof(double2);
   size_t total = half * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1) + 1);  // X_s, P_s, Q, T (+ B), tmp
-  if (pair_shifts_width(c, m, n_shifts)) total += half;                                     // second residual buffer
+  total += half * (pair_shifts_depth(c, m, n_shifts) - 1);                                  // further residual buffers
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                  // links
   total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
   *bytes_out = total;
@@ -1829,12 +1854,10 @@ struct bcg_sbcgrq_state {
   int iter = 0;
   CMat q_rinv;          // deferred normalisation (lazy_q_width): the stored Q times this is the reference's Q
   bool q_lazy = false;
-  // pair_shifts_width: the updates of the shifts >= 1 of the previous iteration wait for this one
-  bcg_field* Qspare = nullptr;           // second residual buffer; after a paired iteration Q and Qspare have swapped
-  bool pending = false;
-  int pend_active = 0;                   // n_active of the deferred iteration
-  std::vector<CMat> pend_A, pend_B;      // its coefficients, by shift
-  CMat pend_rinv;                        // its rho^-1
+  // pair_shifts_depth > 1: iterations whose updates of the shifts >= 1 wait for a later phase C, oldest first
+  std::vector<DeferredIteration> pending;
+  std::vector<bcg_field*> Qfree;         // residual buffers not in use (depth - 1 of them when nothing is pending)
+  int depth = 1;
 };
 
 namespace {
@@ -1842,8 +1865,12 @@ namespace {
 void sbcgrq_release(bcg_sbcgrq_state* st) {
   if (st->T) bcg_field_destroy(st->T);
   if (st->Q && st->Q != st->B) bcg_field_destroy(st->Q);
-  if (st->Qspare && st->Qspare != st->B) bcg_field_destroy(st->Qspare);
-  st->Qspare = nullptr;
+  for (bcg_field* q : st->Qfree)
+    if (q != st->B) bcg_field_destroy(q);
+  for (const DeferredIteration& d : st->pending)
+    if (d.Q != st->B && d.Q != st->Q) bcg_field_destroy(d.Q);
+  st->Qfree.clear();
+  st->pending.clear();
   for (bcg_field* p : st->P)
     if (p) bcg_field_destroy(p);
   st->T = st->Q = nullptr;
@@ -1866,9 +1893,11 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   const CMat alpha_delta = st->alpha * st->delta;        // :145 uses delta of the previous iteration
   // Q -= T alpha ; Gram matrix of the new Q                                  :148, :152
   CMat G2;
-  if (st->pending) {  // the old block is still needed by this iteration's phase C: the new one goes to the other buffer
-    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, &st->q_rinv, st->Qspare));           // global reduction #2
-    std::swap(st->Q, st->Qspare);
+  if (!st->pending.empty()) {  // the old block is needed by a later phase C: the new one goes to another buffer
+    bcg_field* out = st->Qfree.back();
+    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, &st->q_rinv, out));                  // global reduction #2
+    st->Qfree.pop_back();
+    st->Q = out;  // the old buffer stays with pending.back()
   } else {
     BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
   }
@@ -1925,19 +1954,22 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
     if (residual_shift < st->eps_shifts) --st->n_unconverged;  // :179-181
   }
   const bool lazy = lazy_q_width(c, m);
-  if (st->pending) {
-    // Q = this iteration's un-normalised block, Qspare = the deferred iteration's (phase B above swapped them)
-    BCG_TRY(phase_C_pair(c, st->Qspare, st->pend_rinv, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag,
-                         st->pend_active, n_active, st->pend_A, st->pend_B, A_by_shift, B_by_shift, &st->q_rinv));
-    st->pending = false;
-  } else if (st->Qspare && n_active >= 2 && more_follow && st->residual > st->eps) {
-    // another iteration is certain: shift 0 now, the others together with the next iteration's updates
+  const bool next_certain = more_follow && st->residual > st->eps;
+  if (static_cast<int>(st->pending.size()) + 1 < st->depth && next_certain && n_active >= 2) {
+    // shift 0 now, the others in a later iteration's pass (phase_C_multi)
     BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), 1, Acoef, Bcoef, &st->q_rinv));
-    st->pending = true;
-    st->pend_active = n_active;
-    st->pend_A = A_by_shift;
-    st->pend_B = B_by_shift;
-    st->pend_rinv = st->q_rinv;
+    DeferredIteration d;
+    d.Q = st->Q;
+    d.rinv = st->q_rinv;
+    d.n_active = n_active;
+    d.A = A_by_shift;
+    d.B = B_by_shift;
+    st->pending.push_back(d);
+  } else if (!st->pending.empty()) {
+    BCG_TRY(phase_C_multi(c, st->pending, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag, n_active,
+                          A_by_shift, B_by_shift, &st->q_rinv));
+    for (const DeferredIteration& d : st->pending) st->Qfree.push_back(d.Q);
+    st->pending.clear();
   } else {
     BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
                     lazy ? &st->q_rinv : nullptr));
@@ -2006,10 +2038,16 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
 #undef BEGIN_TRY
   st->alpha_s.assign(n_shifts, Identity);  // :122
   st->beta_s.assign(n_shifts, Identity);   // :123
-  if (pair_shifts_width(c, m, n_shifts) && create_like(c, B, &st->Qspare) != BCG_OK) {
-    st->Qspare = nullptr;  // no room for the second residual buffer: every iteration updates every shift
-    (void)hipGetLastError();
-    c->err.clear();
+  st->depth = pair_shifts_depth(c, m, n_shifts);
+  for (int k = 1; k < st->depth; ++k) {
+    bcg_field* q = nullptr;
+    if (create_like(c, B, &q) != BCG_OK) {  // no room for another residual buffer: a smaller depth
+      (void)hipGetLastError();
+      c->err.clear();
+      st->depth = k;
+      break;
+    }
+    st->Qfree.push_back(q);
   }
   st->iter = 0;                            // :126
   st->b_norm = st->delta.row_norms();      // :130

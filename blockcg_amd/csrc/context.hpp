@@ -70,7 +70,7 @@ struct bcg_context {
   size_t field_stagger = 0;              // bytes: field k of a context starts (k mod 16) * stagger into its allocation (BCG_FIELD_STAGGER)
   int fields_created = 0;
   int lazy_q = 1;                        // SBCGrQ: deferred normalisation of Q (phase_B in blockcg_capi.hip; BCG_LAZY_Q)
-  bool pair_shifts = true;               // SBCGrQ: shifts >= 1 updated two iterations at a time (pair_shifts_width; BCG_PAIR_SHIFTS)
+  int pair_shifts = 4;                   // SBCGrQ: shifts >= 1 updated this many iterations at a time (pair_shifts_depth; BCG_PAIR_SHIFTS)
   bool ring_overlap = true;              // capacity mode: overlap the per-chunk exchanges when the callbacks allow (BCG_RING_OVERLAP)
   double2* partials = nullptr;           // block partials of Gram products
   size_t partials_bytes = 0;

@@ -691,28 +691,35 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
   }
 }
 
-// Phase C of TWO consecutive iterations k, k+1 in one pass over the fields of the shifted systems (m = 8, 16).
-// Only P_0 feeds the operator, so the updates of shift s >= 1 of iteration k can wait for iteration k+1 as long as the
-// un-normalised residual block of iteration k is kept (Qold; phase B of k+1 wrote its result to Qnew instead of in place):
-//   q_old = Qold rinv_old ; q_new = Qnew rinv_new                      (neither is stored: deferred normalisation)
-//   entry e < n0          (shift 0, iteration k+1 only):  X += P A ; P <- P B + q_new
-//   n0 <= e < n0 + n2     (both iterations):              X += P A1 ; P <- P B1 + q_old ; X += P A2 ; P <- P B2 + q_new
-//   the n1 entries after  (left the active set at k+1):   X += P A1 ; P <- P B1 + q_old
-// with the intermediate X, P in registers.  Every product is the instruction sequence of k_phaseC on the same fp64
-// values (a store and a load between the two steps would not change them), so the fields are bit-identical to two
-// k_phaseC passes; X_s and P_s are read and written once instead of twice.
-// mats: [rinv_old, rinv_new, then per entry A, B (one step) or A1, B1, A2, B2 (two steps)], consecutive.
-// NW = 12: one block per CU, 3 waves per SIMD (168 registers: two residual tiles, the entry's and the next entry's
-// P and X tiles, two accumulators), whatever the matrices take of the CU's LDS (up to 32 of them at 8 shifts).
-template <int M, int NW>
+// Phase C of NS = 2 .. 4 consecutive iterations in one pass over the fields of the shifted systems (m = 8, 16).
+// Only P_0 feeds the operator, so the updates of the shifts s >= 1 of an iteration can wait for a later one as long as
+// that iteration's un-normalised residual block is kept (phase B of the following iteration then writes its result to
+// another buffer instead of in place).  Step j = 0 .. NS-1 stands for the j-th of the iterations, the last being the
+// current one:
+//   q_j = Q_j rinv_j                                   (not stored: deferred normalisation)
+//   entry e, for its steps j = first[e] .. last[e]-1:   X_e += P_e A_ej ;  P_e <- P_e B_ej + q_j
+// with the intermediate X, P in registers.  Shift 0 was updated in every iteration and takes the last step only; a shift
+// that left the active set on the way takes the steps before that.  Every product is the instruction sequence of
+// k_phaseC on the same fp64 values (a store and a load between two steps would not change them), so the fields are
+// bit-identical to NS k_phaseC passes; X_s and P_s are read and written once instead of NS times.
+// mats: [rinv_0 .. rinv_{NS-1}, then per entry and per step of it A, B], consecutive.
+struct MultiQ {
+  const double2* q[4];
+};
+struct MultiSteps {
+  int first[8], last[8];
+};
+// Blocks: one per CU whatever the matrices take of its LDS.  m = 16: 8 waves, 2 per SIMD -- NS residual tiles, the
+// entry's and the next entry's P and X tiles, two accumulators and the LDS operands in flight are 180 .. 250 registers
+// (12 waves at 168 registers spilled and were 1-2 % slower at NS = 2: 56.7 against 55.5-56.1 ms per iteration).  With the
+// fields read once per NS iterations the kernel is bound by the fp64 matrix pipe as much as by HBM (NS = 4, 4 shifts:
+// 54 TFLOP/s of the 78.6 this chip issues, tools/microbench/mfma_f64_rate.hip, next to 4.5 TB/s).
+template <int M, int NW, int NS>
 __global__ void __launch_bounds__(NW * 64)
-k_phaseC_pair(int64_t rows, const double2* __restrict__ Qold, const double2* __restrict__ Qnew, ShiftPtrs sp, int n0, int n2,
-              int n1, const double2* __restrict__ mats) {
+k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps, int nmat, const double2* __restrict__ mats) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nent = n0 + n2 + n1;
-  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
   for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k) * M * M, tid, NW * 64);
   __syncthreads();
   const int r = lane & 15, kq = lane >> 4;
@@ -720,47 +727,39 @@ k_phaseC_pair(int64_t rows, const double2* __restrict__ Qold, const double2* __r
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
     const int64_t row = tile * 16 + r;
     const bool ok = row < rows;
-    Tile<M> qo, qn, p, x;
-    tile_load<M>(qo, Qold, row, kq, ok);
-    tile_load<M>(qn, Qnew, row, kq, ok);
+    Tile<M> q[NS], p, x;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) tile_load<M>(q[j], qs.q[j], row, kq, ok);
     if (nent > 0) {
       tile_load<M>(p, sp.P[0], row, kq, ok);
       tile_load<M>(x, sp.X[0], row, kq, ok);
     }
-    {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
       Acc<M> A;
       acc_zero<M>(A);
-      rmul_acc<M>(A, qo, smem, lane);
-      tile_from_acc<M>(qo, A);
-      acc_zero<M>(A);
-      rmul_acc<M>(A, qn, smem + MD, lane);
-      tile_from_acc<M>(qn, A);
+      rmul_acc<M>(A, q[j], smem + j * MD, lane);
+      tile_from_acc<M>(q[j], A);
     }
-    const double* mat = smem + 2 * MD;
+    const double* mat = smem + NS * MD;
     for (int e = 0; e < nent; ++e) {
       Tile<M> pn, xn;
       if (e + 1 < nent) {  // the next entry's tiles are in flight while this one is multiplied
         tile_load<M>(pn, sp.P[e + 1], row, kq, ok);
         tile_load<M>(xn, sp.X[e + 1], row, kq, ok);
       }
-      const bool first_step = e >= n0, second_step = e < n0 + n2;  // wave-uniform
-      if (first_step) {
-        Acc<M> AX, AP;
-        acc_from_tile<M>(AX, x);
-        acc_from_tile<M>(AP, qo);
-        rmul_acc2<M>(AX, mat, AP, mat + MD, p, lane);
-        tile_from_acc<M>(x, AX);
-        tile_from_acc<M>(p, AP);
-        mat += 2 * MD;
-      }
-      if (second_step) {
-        Acc<M> AX, AP;
-        acc_from_tile<M>(AX, x);
-        acc_from_tile<M>(AP, qn);
-        rmul_acc2<M>(AX, mat, AP, mat + MD, p, lane);
-        tile_from_acc<M>(x, AX);
-        tile_from_acc<M>(p, AP);
-        mat += 2 * MD;
+      const int first = steps.first[e], last = steps.last[e];  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (j >= first && j < last) {
+          Acc<M> AX, AP;
+          acc_from_tile<M>(AX, x);
+          acc_from_tile<M>(AP, q[j]);
+          rmul_acc2<M>(AX, mat, AP, mat + MD, p, lane);
+          tile_from_acc<M>(x, AX);
+          tile_from_acc<M>(p, AP);
+          mat += 2 * MD;
+        }
       }
       tile_store<M>(x, sp.X[e], row, kq, ok);
       tile_store<M>(p, sp.P[e], row, kq, ok);
@@ -2610,30 +2609,45 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   }
 }
 
-bool phaseC_pair_fits(int m, int n0, int n2, int n1) {
-  if (m != 8 && m != 16) return false;
-  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
+int phaseC_multi_matrices(int nsteps, int nent, const int* first, const int* last) {
+  int n = nsteps;
+  for (int e = 0; e < nent; ++e) n += 2 * (last[e] - first[e]);
+  return n;
+}
+bool phaseC_multi_fits(int m, int nsteps, int n_shifts) {
+  if ((m != 8 && m != 16) || nsteps < 2 || nsteps > 4 || n_shifts < 1 || n_shifts > 8) return false;
+  const int nmat = nsteps + 2 + 2 * nsteps * (n_shifts - 1);  // shift 0 one step, every other shift all of them
   const size_t md = m == 8 ? ((MatLds<8>::DOUBLES + 1) & ~1) : ((MatLds<16>::DOUBLES + 1) & ~1);
-  return n0 + n2 + n1 <= 8 && sizeof(double) * md * nmat <= 150 * 1024;
+  return sizeof(double) * md * nmat <= 150 * 1024;
 }
 
-void launch_phaseC_pair(hipStream_t s, int m, int64_t rows, const double2* Qold, const double2* Qnew, double2* const* X,
-                        double2* const* P, int n0, int n2, int n1, const double2* mats, int max_blocks) {
+void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
+                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks) {
   ShiftPtrs sp{};
-  for (int k = 0; k < n0 + n2 + n1 && k < 8; ++k) {
+  MultiSteps st{};
+  MultiQ qs{};
+  for (int k = 0; k < nent && k < 8; ++k) {
     sp.X[k] = X[k];
     sp.P[k] = P[k];
+    st.first[k] = first[k];
+    st.last[k] = last[k];
   }
-  const int nmat = 2 + 2 * n0 + 4 * n2 + 2 * n1;
-#define BCG_PAIR(MM)                                                                                              \
-  {                                                                                                               \
-    const size_t lds = sizeof(double) * ((MatLds<MM>::DOUBLES + 1) & ~1) * nmat;                                  \
-    const int grid = grid_tiles((rows + 15) / 16, 12, max_blocks / 4 > 0 ? max_blocks / 4 : 1);                   \
-    allow_lds(k_phaseC_pair<MM, 12>, lds);                                                                        \
-    hipLaunchKernelGGL((k_phaseC_pair<MM, 12>), dim3(grid), dim3(768), lds, s, rows, Qold, Qnew, sp, n0, n2, n1, mats);  \
+  for (int j = 0; j < 4; ++j) qs.q[j] = Q[j < nsteps ? j : nsteps - 1];
+  const int nmat = phaseC_multi_matrices(nsteps, nent, first, last);
+  const int cus = max_blocks / 4 > 0 ? max_blocks / 4 : 1;  // one block per CU
+#define BCG_MULTI(MM, NW, NS)                                                                                      \
+  {                                                                                                                \
+    const size_t lds = sizeof(double) * ((MatLds<MM>::DOUBLES + 1) & ~1) * nmat;                                   \
+    const int grid = grid_tiles((rows + 15) / 16, NW, cus);                                                        \
+    allow_lds(k_phaseC_multi<MM, NW, NS>, lds);                                                                    \
+    hipLaunchKernelGGL((k_phaseC_multi<MM, NW, NS>), dim3(grid), dim3(NW * 64), lds, s, rows, qs, sp, nent, st, nmat, mats);  \
   }
-  if (m == 8) BCG_PAIR(8) else BCG_PAIR(16)
-#undef BCG_PAIR
+  if (m == 8) {
+    if (nsteps == 2) BCG_MULTI(8, 12, 2) else if (nsteps == 3) BCG_MULTI(8, 12, 3) else BCG_MULTI(8, 12, 4)
+  } else {
+    if (nsteps == 2) BCG_MULTI(16, 8, 2) else if (nsteps == 3) BCG_MULTI(16, 8, 3) else BCG_MULTI(16, 8, 4)
+  }
+#undef BCG_MULTI
 }
 
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,

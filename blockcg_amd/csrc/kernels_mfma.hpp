@@ -28,12 +28,12 @@ int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2*
 // X[k] += P[k]*mats[1+2k]; P[k] <- P[k]*mats[2+2k] + q.
 void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
                    const double2* mats, int apply_rinv, int max_blocks);
-// Phase C of two consecutive iterations for the shifts that do not feed the operator (kernels_mfma.hip: k_phaseC_pair).
-// Entries: n0 (0 or 1) with one step on q_new, then n2 with both steps, then n1 with one step on q_old.
-// mats = [rinv_old, rinv_new, per entry A, B or A1, B1, A2, B2].
-bool phaseC_pair_fits(int m, int n0, int n2, int n1);
-void launch_phaseC_pair(hipStream_t s, int m, int64_t rows, const double2* Qold, const double2* Qnew, double2* const* X,
-                        double2* const* P, int n0, int n2, int n1, const double2* mats, int max_blocks);
+// Phase C of nsteps = 2 .. 4 consecutive iterations in one pass (kernels_mfma.hip: k_phaseC_multi).  Q[j]: the
+// un-normalised residual block of step j; entry e takes the steps first[e] <= j < last[e].
+// mats = [rinv_0 .. rinv_{nsteps-1}, then per entry and step A, B].
+bool phaseC_multi_fits(int m, int nsteps, int n_shifts);  // LDS room for the matrices of n_shifts shifts
+void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
+                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks);
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,

@@ -622,19 +622,21 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
         assert rel_err(outs[0][0][s], o["X"][s]) < 1e-10
 
 
+@pytest.mark.parametrize("depth", [2, 3, 4])
 @pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
-def test_paired_shift_updates_are_bit_identical(bc, orc, m, dims, monkeypatch):
-    """The shifts >= 1 are updated two iterations at a time (blockcg_capi.hip: pair_shifts_width, k_phaseC_pair).  After any
-    number of iterations -- even, odd, run in one call or in pieces, with shifts leaving the active set on the way -- X,
-    the coefficient trace and the iteration count must equal, bit for bit, those of the solver that updates every shift in
+def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkeypatch):
+    """The shifts >= 1 are updated `depth` iterations at a time (blockcg_capi.hip: pair_shifts_depth, k_phaseC_multi).
+    After any number of iterations -- a multiple of the depth or not, run in one call or in pieces, with shifts leaving the
+    active set on the way -- X and the residual must equal, bit for bit, those of the solver that updates every shift in
     every iteration (BCG_PAIR_SHIFTS=0), and match the oracle."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
     shifts, mass = [0.0, 1e-3, 0.1, 2.0], 0.2
+    S = len(shifts)
     U = orc.fill_gauge(dims, 61)
     Bh = orc.fill_field(m, int(np.prod(dims)), 62)
 
     def run(pair, pieces, eps_shifts):
-        monkeypatch.setenv("BCG_PAIR_SHIFTS", pair)
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
         ctx = bc.Context(dims)
         ctx.profiling(True)
         D = bc.dirac_op(ctx, mass, U=U)
@@ -647,26 +649,28 @@ def test_paired_shift_updates_are_bit_identical(bc, orc, m, dims, monkeypatch):
         st.end()
         return [x.download() for x in X], res, ctx.profile()
 
-    for pieces, eps_shifts in (([6], 0.0), ([7], 0.0), ([2, 3, 1, 4], 0.0), ([1, 1, 1], 0.0), ([9], 3e-2), ([4, 5], 0.5)):
-        a, ra, pa = run("1", pieces, eps_shifts)
-        b, rb, pb = run("0", pieces, eps_shifts)
+    for pieces, eps_shifts in (([12], 0.0), ([7], 0.0), ([2, 3, 1, 4, 5], 0.0), ([1, 1, 1], 0.0), ([9], 3e-2), ([4, 5], 0.5)):
+        a, ra, pa = run(depth, pieces, eps_shifts)
+        b, rb, pb = run(0, pieces, eps_shifts)
         assert ra == rb
-        for s in range(len(shifts)):
+        for s in range(S):
             assert np.array_equal(a[s], b[s]), (pieces, eps_shifts, s)
-        assert "phaseC_pair" not in pb
-        pairs = sum(n // 2 for n in pieces)
+        assert "phaseC_multi" not in pb
         if eps_shifts == 0.0:
-            assert pa.get("phaseC_pair", {}).get("count", 0) == pairs, (pieces, pa.get("phaseC_pair"))
-            # a pair moves 5 + (2 + 4 S) field passes where two plain iterations move 2 (1 + 4 S)
-            S = len(shifts)
-            if pairs:
+            # every call runs its iterations in groups of `depth`, the rest as one smaller group (or a plain iteration)
+            groups = [g for n in pieces for g in [depth] * (n // depth) + [n % depth] if g > 0]
+            multi = [g for g in groups if g >= 2]
+            assert pa.get("phaseC_multi", {}).get("count", 0) == len(multi), (pieces, pa.get("phaseC_multi"))
+            if multi:
+                # a group of g iterations moves 5 (g - 1) + g + 4 S field passes where g plain ones move g (1 + 4 S)
                 per_pass = pb["phaseC"]["bytes"] / (sum(pieces) * (1 + 4 * S))
-                moved = pa["phaseC_pair"]["bytes"] + pa.get("phaseC", {}).get("bytes", 0.0)
-                assert moved == pytest.approx(per_pass * (pairs * (5 + 2 + 4 * S) + (sum(pieces) - 2 * pairs) * (1 + 4 * S)), rel=1e-9)
+                moved = pa["phaseC_multi"]["bytes"] + pa.get("phaseC", {}).get("bytes", 0.0)
+                want = sum(5 * (g - 1) + g + 4 * S if g >= 2 else 1 + 4 * S for g in groups)
+                assert moved == pytest.approx(per_pass * want, rel=1e-9)
     # shifts did leave the active set in the runs with eps_shifts > 0 (otherwise those runs test nothing new)
     o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 3e-2, max_iterations=9, trace_limit=9)
     visited = o["trace"]["residual_shift"][:, 1:] >= 0.0  # -1 = the shift was not updated in that iteration
     assert visited[0].all() and not visited[-1].all()
-    a, _, _ = run("1", [9], 3e-2)
-    for s in range(len(shifts)):
+    a, _, _ = run(depth, [9], 3e-2)
+    for s in range(S):
         assert rel_err(a[s], o["X"][s]) < 1e-10
