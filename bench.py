@@ -34,6 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# fp64 peak, matrix pipe and VALU alike: 256 CUs x 4 SIMDs x 2.4 GHz x 2048 flop per v_mfma_f64_16x16x4_f64 / 64 cycles per
+# issue (tools/microbench/mfma_f64_rate.hip: 65.0 cycles, 77.4 TFLOP/s measured; profiles/r03_group_depth.txt)
+FP64_PEAK_TFLOPS = 78.6
 SHIFTS = [0.0, 1e-6, 1e-4, 1e-2, 1e-5, 1e-3, 1e-1, 1.0]  # SURVEY.md section 8d; first S, sorted
 MASS = 1e-3
 
@@ -334,14 +337,25 @@ def main():
                             sr[kn] = tj[kn]["bytes_per_launch"] / (kernels[kn]["bytes"] / kernels[kn]["count"])
                     stencil_ratio = sr or None
             ach = kb / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_launch_ms": avg_ms, "launches": e["count"], "algorithmic_bytes_per_launch": kb,
-                    "stencil_traffic_ratio": stencil_ratio,
-                    "per_kernel_frac": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                                        for k, v in kernels.items() if v["ms"] > 0}}
-            # algorithmic bytes are a lower bound of the traffic: a fraction above 1 is an accounting error, not a result
-            assert all(f <= 1.0 for f in roof["per_kernel_frac"].values()) and roof["frac"] <= 1.0, roof
+            per_kernel = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for k, v in kernels.items() if v["ms"] > 0}
+            # second roofline: the fp64 flops of the same launches against the chip's fp64 rate (matrix pipe = VALU rate on
+            # gfx950: one v_mfma_f64_16x16x4_f64 per 64 cycles and SIMD, measured by tools/microbench/mfma_f64_rate.hip).
+            # It binds the grouped phase C (k_phaseC_multi), whose fields are read once per several iterations.
+            per_kernel_flop = {k: round(v.get("flops", 0.0) / (v["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+                               for k, v in kernels.items() if v["ms"] > 0}
+            hbm_frac = ach / HBM_PEAK_GBPS
+            tf = e.get("flops", 0.0) / e["count"] / (avg_ms * 1e-3) / 1e12
+            mfma_frac = tf / FP64_PEAK_TFLOPS
+            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac}
+            if mfma_frac > hbm_frac:  # report the roofline that binds this kernel
+                roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_frac}
+            roof.update({"traffic": traffic, "traffic_source": traffic_source,
+                         "avg_launch_ms": avg_ms, "launches": e["count"], "algorithmic_bytes_per_launch": kb,
+                         "flops_per_launch": e.get("flops", 0.0) / e["count"], "hbm_frac": hbm_frac, "fp64_frac": mfma_frac,
+                         "stencil_traffic_ratio": stencil_ratio, "per_kernel_frac": per_kernel,
+                         "per_kernel_fp64_frac": per_kernel_flop})
+            # algorithmic bytes and flops are lower bounds of the work: a fraction above 1 is an accounting error, not a result
+            assert all(f <= 1.0 for f in per_kernel.values()) and all(f <= 1.0 for f in per_kernel_flop.values()), roof
         out = {
             "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
             "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

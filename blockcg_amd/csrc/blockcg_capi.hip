@@ -70,10 +70,13 @@ struct ProfScope {
   // alg_bytes: the ALGORITHMIC HBM bytes of what is launched inside the scope (per-site figure x the
   // sites this launch processes); summed per kernel class so that bench.py's roofline is right for split launches
   // (phase C in two launches, capacity-mode windows) too.
-  ProfScope(bcg_context* ctx, const char* name, double alg_bytes = 0.0) : c(ctx) {
+  // alg_flops: the fp64 flops of the same launches (row kernels: 8 m^2 per row and m x m product on the matrix pipe;
+  // stencil: 576 per site and right-hand side on the VALU) -- the second roofline of the grouped phase C
+  ProfScope(bcg_context* ctx, const char* name, double alg_bytes = 0.0, double alg_flops = 0.0) : c(ctx) {
     if (!c->profiling) return;
     e = &c->prof[name];
     e->bytes += alg_bytes;
+    e->flops += alg_flops;
     a = take();
     b = take();
     (void)hipEventRecord(a, c->stream);
@@ -312,6 +315,16 @@ inline double alg_bytes(const bcg_context* c, int m, double fields, double links
   return static_cast<double>(c->lat.V) * (fields * 48.0 * m + links * 144.0 * c->ndim) * static_cast<double>(num) /
          static_cast<double>(den);
 }
+// the same for `fields` passes over the rows of one field (half-volume fields have half the rows), and the flops of
+// `products` right-multiplications by (or Gram products with) m x m complex matrices over those rows
+inline double row_bytes(const bcg_field* f, double fields) { return static_cast<double>(f->sites) * 48.0 * f->m * fields; }
+inline double product_flops(const bcg_field* f, double products) {
+  return static_cast<double>(f->sites) * 3.0 * f->m * f->m * 8.0 * products;
+}
+inline double hop_flops(const bcg_context* c, int m, bool gram, int64_t num = 1, int64_t den = 1) {
+  return static_cast<double>(c->lat.V) * m * (72.0 * 2 * c->ndim + (gram ? 24.0 * m : 0.0)) * static_cast<double>(num) /
+         static_cast<double>(den);
+}
 inline size_t field_bytes(const bcg_context* c, int m) { return static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2); }
 inline size_t field_bytes(const bcg_field* f) { return static_cast<size_t>(f->sites) * 3 * f->m * sizeof(double2); }
 
@@ -538,7 +551,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     int nb1, nb2;
     note_stencil_form(c, m, 1, bcg::HopWindow());
     {
-      ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));  // both tile classes: counted here
+      ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1), hop_flops(c, m, gram));  // both tile classes: counted here
       nb1 = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                  p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, /*interior*/ 1);
     }
@@ -568,13 +581,13 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
     // one whole launch of a column form: the kernel's last blocks sum the Gram partials themselves (no reduction launch)
     const bool fold = gram && gram_folded && bcg::hop_folds_gram(m, c->lat, kFastBlocks, tune, bcg::HopWindow());
     if (fold) tune.fold = bcg::GramFold{c->dev_gram, c->fold_tickets};
-    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
+    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1), hop_flops(c, m, gram));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                                         p ? p->d : nullptr, c0, c->partials, gram, kFastBlocks, tune, 0);
     if (gram) *gram_blocks = nb;
     if (fold) *gram_folded = true;
   } else {
-    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1));
+    ProfScope ps(c, name, alg_bytes(c, m, mode == bcg::HOP_PLAIN ? 2 : 3, 1), hop_flops(c, m, gram));
     bcg::launch_hop_generic(c->stream, m, c->lat, g->U, g->Ughost, in->d, c->halo_recv, out->d, mode,
                             p ? p->d : nullptr, c0);
   }
@@ -886,7 +899,7 @@ int phase_B(bcg_context* c, bcg_field* Q, const bcg_field* T, const CMat& alpha,
   BCG_TRY(upload_mats(c, m, two, rinv_prev ? 2 : 1, &Md));
   int nb;
   {
-    ProfScope ps(c, "phaseB", alg_bytes(c, m, 3));
+    ProfScope ps(c, "phaseB", row_bytes(Q, 3), product_flops(Q, rinv_prev ? 3 : 2));  // [rho^-1,] alpha, Gram
     nb = bcg::launch_phaseB(c->stream, m, rows_of(Q), Q->d, T->d, Md, c->partials, c->row_blocks_B,
                             bcg::GramFold{c->dev_gram, c->fold_tickets},
                             rinv_prev ? Md + static_cast<size_t>(m) * m : nullptr, Qout ? Qout->d : nullptr);
@@ -929,7 +942,8 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
     BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
     {
       // the launch that applies rho^-1 reads and writes Q; a later launch of the same iteration (m = 32) re-reads it
-      ProfScope ps(c, "phaseC", alg_bytes(c, m, (first && !rinv_out ? 2 : 1) + 4 * ns));
+      ProfScope ps(c, "phaseC", row_bytes(Q, (first && !rinv_out ? 2 : 1) + 4 * ns),
+                   product_flops(Q, (rinv_out || first ? 1 : 0) + 2 * ns));
       bcg::launch_phaseC(c->stream, m, rows_of(Q), Q->d, Xp, Pp, ns, Md, rinv_out ? 2 : first, c->row_blocks_C);
     }
     BCG_TRY(check_launch(c, "phaseC"));
@@ -1002,7 +1016,7 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
   const double2* Md;
   BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
   {
-    ProfScope ps(c, "phaseC_multi", alg_bytes(c, m, ns + 4 * n));
+    ProfScope ps(c, "phaseC_multi", row_bytes(Qnew, ns + 4 * n), product_flops(Qnew, static_cast<double>(mats.size() - ns) + ns));
     bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C);
   }
   BCG_TRY(check_launch(c, "phaseC_multi"));
@@ -1256,7 +1270,7 @@ const char* bcg_profile_json(bcg_context* c) {
     if (!first) os << ", ";
     first = false;
     os << "\"" << kv.first << "\": {\"ms\": " << kv.second.ms << ", \"count\": " << kv.second.count
-       << ", \"bytes\": " << kv.second.bytes << "}";
+       << ", \"bytes\": " << kv.second.bytes << ", \"flops\": " << kv.second.flops << "}";
   }
   os << "}";
   c->prof_json = os.str();

@@ -33,6 +33,7 @@ struct ProfEntry {
   double ms = 0.0;
   long count = 0;
   double bytes = 0.0;  // algorithmic HBM bytes of the launches timed under this name
+  double flops = 0.0;  // their fp64 flops (0 where not accounted)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 

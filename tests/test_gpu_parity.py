@@ -489,7 +489,9 @@ def test_capacity_mode_matches_default_and_oracle(bc, orc, m, dims, ring, walk, 
         assert rel_err(res[ring][1][s], res[0][1][s]) < 1e-11
         assert rel_err(res[ring][1][s], o["X"][s]) < 1e-10
     field = V * 3 * m * 16
-    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring  # what the mode is for
+    # what the mode is for: the ring instead of the intermediate field, and none of the three further residual buffers of
+    # the grouped shift updates (pair_shifts_depth: m = 8, 16, depth 4), which trade memory for passes
+    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (3 * field if m in (8, 16) else 0)
 
 
 def test_capacity_mode_arguments(bc):
