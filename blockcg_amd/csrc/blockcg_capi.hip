@@ -1016,7 +1016,9 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
   const double2* Md;
   BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
   {
-    ProfScope ps(c, "phaseC_multi", row_bytes(Qnew, ns + 4 * n), product_flops(Qnew, static_cast<double>(mats.size() - ns) + ns));
+    // one profile entry per group size: each is its own kernel instantiation (k_phaseC_multi<m, waves, ns>)
+    static const char* const names[5] = {"", "", "phaseC_multi2", "phaseC_multi3", "phaseC_multi4"};
+    ProfScope ps(c, names[ns], row_bytes(Qnew, ns + 4 * n), product_flops(Qnew, static_cast<double>(mats.size() - ns) + ns));
     bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C);
   }
   BCG_TRY(check_launch(c, "phaseC_multi"));
