@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: a long full-size solve (64^4, m = 16, 4 shifts, mass 0.05, eps 1e-10) with the true residuals recomputed
 independently, then the same solve as two half-volume solves.  Last run (profiles/r03_soak_solve.txt): 954 iterations in
-60.7 s (63.6 ms each), max true residual 9.9e-11 on every shift; half-volume: 952 + 952 iterations in 63.2 s, same residuals."""
+49.1 s (51.5 ms each), max true residual 9.9e-11 on every shift; half-volume: 952 + 952 iterations in 53.5 s, same residuals."""
 import os
 import sys
 import time
