@@ -190,8 +190,8 @@ def resolve_shape(world, local_dims, capacity):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)  # a multiple of the depth the shift updates are grouped over (4)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--local-dims", type=int, nargs="+", default=None,
                     help="sites per GPU (default: 64 64 64 64 on one GPU, 64 64 64 128 on several)")
     ap.add_argument("--m", type=int, default=16)
