@@ -958,12 +958,15 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
 // that ends the group (the `depth`-th iteration, or the last one before the loop can stop) applies every deferred
 // iteration's updates and its own to the shifts >= 1 with X_s, P_s read and written once.  Same kernel arithmetic on the
 // same values in the same order: the fields the caller sees after any number of iterations are bit-identical.  Per group
-// of D iterations phase C moves (5 (D-1) + D + 4 S) s instead of D (1 + 4 S) s; D - 1 more fields of memory, so not in
-// capacity mode.  BCG_PAIR_SHIFTS=<depth> (0 or 1: off; default 4, the largest instantiated).  Measured at 64^4,
+// of D iterations phase C moves (5 (D-1) + D + 4 S) s instead of D (1 + 4 S) s.
+// Memory: D - 2 further fields.  The phase B of the iteration that closes a full group writes the new residual block over
+// T, which it reads tile by tile just before (T is dead from there to the next operator application), and one of the
+// residual buffers the group releases becomes the next T.  So D = 2 costs no memory at all and is what capacity mode
+// runs.  BCG_PAIR_SHIFTS=<depth> (0 or 1: off; default 4, the largest instantiated).  Measured at 64^4,
 // m = 16, 4 shifts: 67.0 ms per iteration without, 55.5-56.1 at depth 2, 54.3 at 3, 53.4-53.7 at 4 (profiles/r03_group_depth.txt).
 int pair_shifts_depth(const bcg_context* c, int m, int n_shifts) {
-  if (c->pair_shifts < 2 || !lazy_q_width(c, m) || !(m == 8 || m == 16) || n_shifts < 2 || capacity_path(c, m)) return 1;
-  int d = std::min(c->pair_shifts, 4);
+  if (c->pair_shifts < 2 || !lazy_q_width(c, m) || !(m == 8 || m == 16) || n_shifts < 2) return 1;
+  int d = std::min(c->pair_shifts, capacity_path(c, m) ? 2 : 4);
   while (d >= 2 && !bcg::phaseC_multi_fits(m, d, n_shifts)) --d;
   return d;
 }
@@ -1316,7 +1319,7 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
   const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
   size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
-  total += field * (pair_shifts_depth(c, m, n_shifts) - 1);                               // further residual buffers
+  total += field * std::max(0, pair_shifts_depth(c, m, n_shifts) - 2);                    // further residual buffers
   total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
   total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
@@ -1333,7 +1336,7 @@ int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int 
   if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
   const size_t half = static_cast<size_t>(c->lat.V / 2) * 3 * m * sizeof(double2);
   size_t total = half * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1) + 1);  // X_s, P_s, Q, T (+ B), tmp
-  total += half * (pair_shifts_depth(c, m, n_shifts) - 1);                                  // further residual buffers
+  total += half * std::max(0, pair_shifts_depth(c, m, n_shifts) - 2);                       // further residual buffers
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                  // links
   total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
   *bytes_out = total;
@@ -1872,14 +1875,14 @@ struct bcg_sbcgrq_state {
   bool q_lazy = false;
   // pair_shifts_depth > 1: iterations whose updates of the shifts >= 1 wait for a later phase C, oldest first
   std::vector<DeferredIteration> pending;
-  std::vector<bcg_field*> Qfree;         // residual buffers not in use (depth - 1 of them when nothing is pending)
+  std::vector<bcg_field*> Qfree;         // residual buffers not in use (depth - 2 of them when nothing is pending)
   int depth = 1;
 };
 
 namespace {
 
 void sbcgrq_release(bcg_sbcgrq_state* st) {
-  if (st->T) bcg_field_destroy(st->T);
+  if (st->T && st->T != st->B) bcg_field_destroy(st->T);  // T, Q and the spare buffers rotate: any of them may be B's storage
   if (st->Q && st->Q != st->B) bcg_field_destroy(st->Q);
   for (bcg_field* q : st->Qfree)
     if (q != st->B) bcg_field_destroy(q);
@@ -1910,9 +1913,13 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   // Q -= T alpha ; Gram matrix of the new Q                                  :148, :152
   CMat G2;
   if (!st->pending.empty()) {  // the old block is needed by a later phase C: the new one goes to another buffer
-    bcg_field* out = st->Qfree.back();
+    // ... a spare one, or, in the iteration that closes a full group, T itself: phase B reads each tile of T just before
+    // it writes the same tile of the new Q, and T is not read again before the next operator application rewrites it
+    const bool over_T = st->Qfree.empty();
+    bcg_field* out = over_T ? st->T : st->Qfree.back();
     BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, &st->q_rinv, out));                  // global reduction #2
-    st->Qfree.pop_back();
+    if (over_T) st->T = nullptr;  // one of the group's buffers takes its place below
+    else st->Qfree.pop_back();
     st->Q = out;  // the old buffer stays with pending.back()
   } else {
     BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
@@ -1984,7 +1991,10 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   } else if (!st->pending.empty()) {
     BCG_TRY(phase_C_multi(c, st->pending, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag, n_active,
                           A_by_shift, B_by_shift, &st->q_rinv));
-    for (const DeferredIteration& d : st->pending) st->Qfree.push_back(d.Q);
+    for (const DeferredIteration& d : st->pending) {
+      if (!st->T) st->T = d.Q;
+      else st->Qfree.push_back(d.Q);
+    }
     st->pending.clear();
   } else {
     BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
@@ -2055,7 +2065,7 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
   st->alpha_s.assign(n_shifts, Identity);  // :122
   st->beta_s.assign(n_shifts, Identity);   // :123
   st->depth = pair_shifts_depth(c, m, n_shifts);
-  for (int k = 1; k < st->depth; ++k) {
+  for (int k = 2; k < st->depth; ++k) {  // depth 2 needs none (T doubles as the second residual buffer)
     bcg_field* q = nullptr;
     if (create_like(c, B, &q) != BCG_OK) {  // no room for another residual buffer: a smaller depth
       (void)hipGetLastError();

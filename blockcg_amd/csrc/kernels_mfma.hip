@@ -493,8 +493,9 @@ __device__ __forceinline__ void gram_fold(const GramFold& gf, double2* __restric
 template <int M>
 // rinv != nullptr (deferred normalisation, see phase_B in blockcg_capi.hip): the stored Q is the previous iteration's
 // un-normalised block; it is multiplied by rinv = rho_prev^-1 first -- the arithmetic phase C used to do before storing it.
-// Qout: where the new Q goes (== Q: in place; another buffer when the old block must survive, see k_phaseC_pair).
-__global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, const double2* __restrict__ T,
+// Qout: where the new Q goes (== Q: in place; another buffer when the old block must survive, see k_phaseC_multi; that
+// buffer may be T itself: every wave has read its tile of T when it writes that tile, and no other wave touches it).
+__global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, const double2* T,
                                                 const double2* __restrict__ negalpha, double2* __restrict__ partials,
                                                 GramFold gf, const double2* __restrict__ rinv, double2* Qout) {
   constexpr int NW = 4;
@@ -2482,7 +2483,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma8(int64_t rows, const double2*
 
 // Phase B at m = 8: Q += T * negalpha through the m = 8 product tile, then the new 16 x 8 tile is re-read from a per-wave
 // LDS buffer in (row, column) ownership for the folded Gram product.
-__global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, const double2* Q, const double2* __restrict__ T,
+__global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, const double2* Q, const double2* T,
                                                  const double2* __restrict__ negalpha, double2* __restrict__ partials,
                                                  const double2* __restrict__ rinv, double2* Qout) {
   constexpr int M = 8, NW = 4;

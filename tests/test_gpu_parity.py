@@ -489,9 +489,9 @@ def test_capacity_mode_matches_default_and_oracle(bc, orc, m, dims, ring, walk, 
         assert rel_err(res[ring][1][s], res[0][1][s]) < 1e-11
         assert rel_err(res[ring][1][s], o["X"][s]) < 1e-10
     field = V * 3 * m * 16
-    # what the mode is for: the ring instead of the intermediate field, and none of the three further residual buffers of
-    # the grouped shift updates (pair_shifts_depth: m = 8, 16, depth 4), which trade memory for passes
-    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (3 * field if m in (8, 16) else 0)
+    # what the mode is for: the ring instead of the intermediate field, and none of the two further residual buffers of
+    # the shift updates grouped over four iterations (pair_shifts_depth: m = 8, 16; capacity mode groups two, for free)
+    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (2 * field if m in (8, 16) else 0)
 
 
 def test_capacity_mode_arguments(bc):
@@ -676,4 +676,43 @@ def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkey
     assert visited[0].all() and not visited[-1].all()
     a, _, _ = run(depth, [9], 3e-2)
     for s in range(S):
+        assert rel_err(a[s], o["X"][s]) < 1e-10
+
+
+@pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 4), (8, [32, 4, 4, 8], 4)], ids=["m16", "m8"])
+def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypatch):
+    """Capacity mode groups the shift updates over two iterations: that depth needs no memory (the phase B that closes a
+    pair writes the new residual block over T and a released buffer becomes the next T).  Bit-identical to the ungrouped
+    solver in the same mode, for even and odd iteration counts and with the caller's B consumed or kept."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    shifts, mass = [0.0, 1e-3, 0.1], 0.2
+    U = orc.fill_gauge(dims, 71)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 72)
+
+    def run(pair, iters, consume):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+        ctx = bc.Context(dims)
+        ctx.capacity_mode(ring)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0, consume_B=consume)
+        st.iterate(iters)
+        res = st.residual
+        st.end()
+        return [x.download() for x in X], res, ctx.profile(), ctx.sbcgrq_device_bytes(m, len(shifts), consume_B=consume), B.download()
+
+    for iters, consume in ((6, True), (7, False), (1, True)):
+        a, ra, pa, mem_a, Ba = run(4, iters, consume)  # asks for four, capacity mode grants two
+        b, rb, pb, mem_b, Bb = run(0, iters, consume)
+        assert ra == rb and mem_a == mem_b
+        for s in range(len(shifts)):
+            assert np.array_equal(a[s], b[s]), (iters, consume, s)
+        assert pa.get("phaseC_multi2", {}).get("count", 0) == iters // 2 and "phaseC_multi4" not in pa
+        if not consume:
+            assert np.array_equal(Ba, Bh) and np.array_equal(Bb, Bh)  # the rotation of T, Q never touches the caller's B
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=6)
+    a, _, _, _, _ = run(4, 6, True)
+    for s in range(len(shifts)):
         assert rel_err(a[s], o["X"][s]) < 1e-10
