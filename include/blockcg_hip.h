@@ -128,10 +128,11 @@ int bcg_force_generic(bcg_context* ctx, int enable);
 int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
 /* Device memory one SBCGrQ solve of width m with n_shifts shifts occupies on this rank in the current mode: X_s, P_s,
  * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch -- and, outside capacity mode
- * at m = 8 and 16 with two or more shifts, up to three further residual buffers: the solver then updates X_s, P_s of the
+ * at m = 8 and 16 with two or more shifts, up to two further residual buffers: the solver updates X_s, P_s of the
  * shifts s >= 1 (inc/block_solvers.hpp:161-181) up to four iterations at a time, which needs the residual block of
- * each deferred iteration (results bit-identical; a solve that cannot allocate them runs with fewer; BCG_PAIR_SHIFTS=0
- * at context creation switches the grouping off).  Host arithmetic only. */
+ * each deferred iteration (two at a time, as in capacity mode, need none: T doubles as the second buffer).  Results are
+ * bit-identical; a solve that cannot allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation
+ * switches the grouping off.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
 /* ... and one HALF-VOLUME solve (bcg_field_create_half below: all work fields hold V/2 sites, links stay full-volume) */
 int bcg_sbcgrq_device_bytes_half(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
