@@ -965,7 +965,8 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
 // runs.  BCG_PAIR_SHIFTS=<depth> (0 or 1: off; default 4, the largest instantiated).  Measured at 64^4,
 // m = 16, 4 shifts: 67.0 ms per iteration without, 55.5-56.1 at depth 2, 54.3 at 3, 53.4-53.7 at 4 (profiles/r03_group_depth.txt).
 int pair_shifts_depth(const bcg_context* c, int m, int n_shifts) {
-  if (c->pair_shifts < 2 || !lazy_q_width(c, m) || !(m == 8 || m == 16) || n_shifts < 2) return 1;
+  if (c->pair_shifts < 2 || n_shifts < 2 || !fast_rows(c, m) || !fast_rmul(c, m)) return 1;
+  if (!lazy_q_width(c, m) && m != 32) return 1;  // m = 8, 16 group the un-normalised blocks; m = 32 the stored ones, in pairs
   int d = std::min(c->pair_shifts, capacity_path(c, m) ? 2 : 4);
   while (d >= 2 && !bcg::phaseC_multi_fits(m, d, n_shifts)) --d;
   return d;
@@ -979,53 +980,73 @@ struct DeferredIteration {
   std::vector<CMat> A, B;        // their coefficients, by shift
 };
 
-// The deferred iterations' updates and the current one's (coefficients A0/B0 for shift 0, Anew/Bnew by shift for the rest)
+// The deferred iterations' updates and the current one's (coefficients A0/B0 for shift 0, Anew/Bnew by shift for the rest).
+// rinv_out != nullptr (deferred normalisation, m = 8, 16): the blocks are un-normalised and one launch does everything.
+// nullptr (m = 32): the blocks are stored normalised -- the current one by the ordinary phase C launch that also updates
+// shift 0 -- and the shifts >= 1 follow in launches of as many shifts as have room for their matrices in LDS.
 int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bcg_field* Qnew, const CMat& rho_new,
                   bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_new,
                   const std::vector<CMat>& Anew, const std::vector<CMat>& Bnew, CMat* rinv_out) {
   const int m = Qnew->m, ns = static_cast<int>(pend.size()) + 1;
+  const bool lazy = rinv_out != nullptr;
   const CMat rinv_new = bcg::upper_triangular_inverse(rho_new);
-  std::vector<const CMat*> mats;
   const double2* Qd[4];
-  for (int j = 0; j + 1 < ns; ++j) {
-    mats.push_back(&pend[j].rinv);
-    Qd[j] = pend[j].Q->d;
-  }
-  mats.push_back(&rinv_new);
+  for (int j = 0; j + 1 < ns; ++j) Qd[j] = pend[j].Q->d;
   Qd[ns - 1] = Qnew->d;
-  double2* Xp[8];
-  double2* Pp[8];
-  int first[8], last[8], n = 0;
-  Xp[n] = X[0]->d;
-  Pp[n] = P[0]->d;
-  first[n] = ns - 1;
-  last[n++] = ns;
-  mats.push_back(&A0);
-  mats.push_back(&B0);
+  struct Entry {
+    int shift, first, last;
+    std::vector<const CMat*> mats;
+  };
+  std::vector<Entry> entries;
+  if (lazy) {
+    entries.push_back(Entry{0, ns - 1, ns, {&A0, &B0}});
+  } else {
+    const std::vector<CMat> a0(1, A0), b0(1, B0);
+    BCG_TRY(phase_C(c, Qnew, rho_new, X, P, 1, a0, b0, nullptr));  // Q <- Q rho^-1 stored; shift 0
+  }
   for (int s = 1; s < pend[0].n_active; ++s) {  // the active set only shrinks: a shift takes a prefix of the steps
-    int steps = 0;
+    Entry e{s, 0, 0, {}};
     for (int j = 0; j < ns; ++j) {
       const bool on = s < (j + 1 < ns ? pend[j].n_active : n_active_new);
       if (!on) break;
-      mats.push_back(j + 1 < ns ? &pend[j].A[s] : &Anew[s]);
-      mats.push_back(j + 1 < ns ? &pend[j].B[s] : &Bnew[s]);
-      ++steps;
+      e.mats.push_back(j + 1 < ns ? &pend[j].A[s] : &Anew[s]);
+      e.mats.push_back(j + 1 < ns ? &pend[j].B[s] : &Bnew[s]);
+      ++e.last;
     }
-    Xp[n] = X[s]->d;
-    Pp[n] = P[s]->d;
-    first[n] = 0;
-    last[n++] = steps;
+    entries.push_back(e);
   }
-  const double2* Md;
-  BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
-  {
-    // one profile entry per group size: each is its own kernel instantiation (k_phaseC_multi<m, waves, ns>)
-    static const char* const names[5] = {"", "", "phaseC_multi2", "phaseC_multi3", "phaseC_multi4"};
-    ProfScope ps(c, names[ns], row_bytes(Qnew, ns + 4 * n), product_flops(Qnew, static_cast<double>(mats.size() - ns) + ns));
-    bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C);
+  const int per_launch = lazy ? 8 : bcg::phaseC_multi_max_entries(m, ns, false);
+  static const char* const names[5] = {"", "", "phaseC_multi2", "phaseC_multi3", "phaseC_multi4"};
+  for (size_t e0 = 0; e0 < entries.size(); e0 += per_launch) {
+    const int n = static_cast<int>(std::min(entries.size() - e0, static_cast<size_t>(per_launch)));
+    std::vector<const CMat*> mats;
+    if (lazy) {
+      for (int j = 0; j + 1 < ns; ++j) mats.push_back(&pend[j].rinv);
+      mats.push_back(&rinv_new);
+    }
+    double2* Xp[8];
+    double2* Pp[8];
+    int first[8], last[8];
+    double products = lazy ? ns : 0;
+    for (int k = 0; k < n; ++k) {
+      const Entry& e = entries[e0 + k];
+      Xp[k] = X[e.shift]->d;
+      Pp[k] = P[e.shift]->d;
+      first[k] = e.first;
+      last[k] = e.last;
+      mats.insert(mats.end(), e.mats.begin(), e.mats.end());
+      products += static_cast<double>(e.mats.size());
+    }
+    const double2* Md;
+    BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
+    {
+      // one profile entry per group size: each is its own kernel instantiation (k_phaseC_multi<m, waves, ns>)
+      ProfScope ps(c, names[ns], row_bytes(Qnew, ns + 4 * n), product_flops(Qnew, products));
+      bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C, lazy);
+    }
+    BCG_TRY(check_launch(c, "phaseC_multi"));
   }
-  BCG_TRY(check_launch(c, "phaseC_multi"));
-  *rinv_out = rinv_new;
+  if (rinv_out) *rinv_out = rinv_new;
   return BCG_OK;
 }
 
@@ -1917,7 +1938,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
     // it writes the same tile of the new Q, and T is not read again before the next operator application rewrites it
     const bool over_T = st->Qfree.empty();
     bcg_field* out = over_T ? st->T : st->Qfree.back();
-    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, &st->q_rinv, out));                  // global reduction #2
+    BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr, out));  // global reduction #2
     if (over_T) st->T = nullptr;  // one of the group's buffers takes its place below
     else st->Qfree.pop_back();
     st->Q = out;  // the old buffer stays with pending.back()
@@ -1980,7 +2001,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   const bool next_certain = more_follow && st->residual > st->eps;
   if (static_cast<int>(st->pending.size()) + 1 < st->depth && next_certain && n_active >= 2) {
     // shift 0 now, the others in a later iteration's pass (phase_C_multi)
-    BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), 1, Acoef, Bcoef, &st->q_rinv));
+    BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), 1, Acoef, Bcoef, lazy ? &st->q_rinv : nullptr));
     DeferredIteration d;
     d.Q = st->Q;
     d.rinv = st->q_rinv;
@@ -1990,7 +2011,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
     st->pending.push_back(d);
   } else if (!st->pending.empty()) {
     BCG_TRY(phase_C_multi(c, st->pending, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag, n_active,
-                          A_by_shift, B_by_shift, &st->q_rinv));
+                          A_by_shift, B_by_shift, lazy ? &st->q_rinv : nullptr));
     for (const DeferredIteration& d : st->pending) {
       if (!st->T) st->T = d.Q;
       else st->Qfree.push_back(d.Q);

@@ -715,7 +715,10 @@ struct MultiSteps {
 // (12 waves at 168 registers spilled and were 1-2 % slower at NS = 2: 56.7 against 55.5-56.1 ms per iteration).  With the
 // fields read once per NS iterations the kernel is bound by the fp64 matrix pipe as much as by HBM (NS = 4, 4 shifts:
 // 54 TFLOP/s of the 78.6 this chip issues, tools/microbench/mfma_f64_rate.hip, next to 4.5 TB/s).
-template <int M, int NW, int NS>
+// NORM = false (m = 32, where the residual block is stored normalised): the Q_j are used as they are and mats holds no
+// rinv_j.  PRE = false: no prefetch of the next entry's tiles (m = 32: a tile is 32 registers, and an entry's two steps
+// are 128 MFMAs per load).
+template <int M, int NW, int NS, bool NORM = true, bool PRE = true>
 __global__ void __launch_bounds__(NW * 64)
 k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps, int nmat, const double2* __restrict__ mats) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -735,17 +738,19 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       tile_load<M>(p, sp.P[0], row, kq, ok);
       tile_load<M>(x, sp.X[0], row, kq, ok);
     }
+    if (NORM) {
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      Acc<M> A;
-      acc_zero<M>(A);
-      rmul_acc<M>(A, q[j], smem + j * MD, lane);
-      tile_from_acc<M>(q[j], A);
+      for (int j = 0; j < NS; ++j) {
+        Acc<M> A;
+        acc_zero<M>(A);
+        rmul_acc<M>(A, q[j], smem + j * MD, lane);
+        tile_from_acc<M>(q[j], A);
+      }
     }
-    const double* mat = smem + NS * MD;
+    const double* mat = smem + (NORM ? NS : 0) * MD;
     for (int e = 0; e < nent; ++e) {
       Tile<M> pn, xn;
-      if (e + 1 < nent) {  // the next entry's tiles are in flight while this one is multiplied
+      if (PRE && e + 1 < nent) {  // the next entry's tiles are in flight while this one is multiplied
         tile_load<M>(pn, sp.P[e + 1], row, kq, ok);
         tile_load<M>(xn, sp.X[e + 1], row, kq, ok);
       }
@@ -765,8 +770,13 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       tile_store<M>(x, sp.X[e], row, kq, ok);
       tile_store<M>(p, sp.P[e], row, kq, ok);
       if (e + 1 < nent) {
-        p = pn;
-        x = xn;
+        if (PRE) {
+          p = pn;
+          x = xn;
+        } else {
+          tile_load<M>(p, sp.P[e + 1], row, kq, ok);
+          tile_load<M>(x, sp.X[e + 1], row, kq, ok);
+        }
       }
     }
   }
@@ -2610,20 +2620,31 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   }
 }
 
-int phaseC_multi_matrices(int nsteps, int nent, const int* first, const int* last) {
-  int n = nsteps;
+int phaseC_multi_matrices(int nsteps, int nent, const int* first, const int* last, bool normalise) {
+  int n = normalise ? nsteps : 0;
   for (int e = 0; e < nent; ++e) n += 2 * (last[e] - first[e]);
   return n;
 }
+static size_t mat_lds_bytes(int m) {
+  return sizeof(double) * (m == 8 ? ((MatLds<8>::DOUBLES + 1) & ~1) : m == 16 ? ((MatLds<16>::DOUBLES + 1) & ~1) : ((MatLds<32>::DOUBLES + 1) & ~1));
+}
 bool phaseC_multi_fits(int m, int nsteps, int n_shifts) {
-  if ((m != 8 && m != 16) || nsteps < 2 || nsteps > 4 || n_shifts < 1 || n_shifts > 8) return false;
+  if (nsteps < 2 || nsteps > 4 || n_shifts < 1 || n_shifts > 8) return false;
+  if (m == 32) return nsteps == 2;  // un-normalised blocks are not kept at m = 32; launches of phaseC_multi_max_entries shifts
+  if (m != 8 && m != 16) return false;
   const int nmat = nsteps + 2 + 2 * nsteps * (n_shifts - 1);  // shift 0 one step, every other shift all of them
-  const size_t md = m == 8 ? ((MatLds<8>::DOUBLES + 1) & ~1) : ((MatLds<16>::DOUBLES + 1) & ~1);
-  return sizeof(double) * md * nmat <= 150 * 1024;
+  return mat_lds_bytes(m) * nmat <= 150 * 1024;
+}
+int phaseC_multi_max_entries(int m, int nsteps, bool normalise) {
+  const int per_entry = 2 * nsteps;
+  const int room = static_cast<int>(150 * 1024 / mat_lds_bytes(m)) - (normalise ? nsteps : 0);
+  const int n = room / per_entry;
+  return n > 8 ? 8 : n;
 }
 
 void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
-                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks) {
+                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks,
+                         bool normalise) {
   ShiftPtrs sp{};
   MultiSteps st{};
   MultiQ qs{};
@@ -2634,19 +2655,21 @@ void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const d
     st.last[k] = last[k];
   }
   for (int j = 0; j < 4; ++j) qs.q[j] = Q[j < nsteps ? j : nsteps - 1];
-  const int nmat = phaseC_multi_matrices(nsteps, nent, first, last);
+  const int nmat = phaseC_multi_matrices(nsteps, nent, first, last, normalise);
   const int cus = max_blocks / 4 > 0 ? max_blocks / 4 : 1;  // one block per CU
-#define BCG_MULTI(MM, NW, NS)                                                                                      \
+#define BCG_MULTI(MM, NW, NS, NORM, PRE)                                                                           \
   {                                                                                                                \
-    const size_t lds = sizeof(double) * ((MatLds<MM>::DOUBLES + 1) & ~1) * nmat;                                   \
+    const size_t lds = mat_lds_bytes(MM) * nmat;                                                                   \
     const int grid = grid_tiles((rows + 15) / 16, NW, cus);                                                        \
-    allow_lds(k_phaseC_multi<MM, NW, NS>, lds);                                                                    \
-    hipLaunchKernelGGL((k_phaseC_multi<MM, NW, NS>), dim3(grid), dim3(NW * 64), lds, s, rows, qs, sp, nent, st, nmat, mats);  \
+    allow_lds(k_phaseC_multi<MM, NW, NS, NORM, PRE>, lds);                                                         \
+    hipLaunchKernelGGL((k_phaseC_multi<MM, NW, NS, NORM, PRE>), dim3(grid), dim3(NW * 64), lds, s, rows, qs, sp, nent, st, nmat, mats);  \
   }
   if (m == 8) {
-    if (nsteps == 2) BCG_MULTI(8, 12, 2) else if (nsteps == 3) BCG_MULTI(8, 12, 3) else BCG_MULTI(8, 12, 4)
+    if (nsteps == 2) BCG_MULTI(8, 12, 2, true, true) else if (nsteps == 3) BCG_MULTI(8, 12, 3, true, true) else BCG_MULTI(8, 12, 4, true, true)
+  } else if (m == 16) {
+    if (nsteps == 2) BCG_MULTI(16, 8, 2, true, true) else if (nsteps == 3) BCG_MULTI(16, 8, 3, true, true) else BCG_MULTI(16, 8, 4, true, true)
   } else {
-    if (nsteps == 2) BCG_MULTI(16, 8, 2) else if (nsteps == 3) BCG_MULTI(16, 8, 3) else BCG_MULTI(16, 8, 4)
+    BCG_MULTI(32, 8, 2, false, false)
   }
 #undef BCG_MULTI
 }

@@ -29,11 +29,13 @@ int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2*
 void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* const* X, double2* const* P, int nshift,
                    const double2* mats, int apply_rinv, int max_blocks);
 // Phase C of nsteps = 2 .. 4 consecutive iterations in one pass (kernels_mfma.hip: k_phaseC_multi).  Q[j]: the
-// un-normalised residual block of step j; entry e takes the steps first[e] <= j < last[e].
-// mats = [rinv_0 .. rinv_{nsteps-1}, then per entry and step A, B].
-bool phaseC_multi_fits(int m, int nsteps, int n_shifts);  // LDS room for the matrices of n_shifts shifts
+// residual block of step j -- un-normalised with normalise = true (m = 8, 16: mats starts with rinv_0 .. rinv_{nsteps-1}),
+// as stored otherwise (m = 32) -- entry e takes the steps first[e] <= j < last[e]; then per entry and step A, B.
+bool phaseC_multi_fits(int m, int nsteps, int n_shifts);  // the grouping is available for this width and depth
+int phaseC_multi_max_entries(int m, int nsteps, bool normalise);  // entries of nsteps steps one launch has LDS room for
 void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
-                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks);
+                         double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks,
+                         bool normalise = true);
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,

@@ -624,8 +624,9 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
         assert rel_err(outs[0][0][s], o["X"][s]) < 1e-10
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
-@pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
+@pytest.mark.parametrize("m,dims,depth", [(16, [16, 8, 8, 8], 2), (16, [16, 8, 8, 8], 3), (16, [16, 8, 8, 8], 4), (8, [16, 8, 4, 8], 2),
+                                          (8, [16, 8, 4, 8], 3), (8, [16, 8, 4, 8], 4), (32, [16, 4, 4, 6], 2)],
+                         ids=["m16-2", "m16-3", "m16-4", "m8-2", "m8-3", "m8-4", "m32-2"])
 def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkeypatch):
     """The shifts >= 1 are updated `depth` iterations at a time (blockcg_capi.hip: pair_shifts_depth, k_phaseC_multi).
     After any number of iterations -- a multiple of the depth or not, run in one call or in pieces, with shifts leaving the
@@ -663,8 +664,10 @@ def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkey
             groups = [g for n in pieces for g in [depth] * (n // depth) + [n % depth] if g > 0]
             multi = [g for g in groups if g >= 2]
             for g in (2, 3, 4):  # one profile entry per group size
-                assert pa.get(f"phaseC_multi{g}", {}).get("count", 0) == multi.count(g), (pieces, g)
-            if multi:
+                assert m == 32 or pa.get(f"phaseC_multi{g}", {}).get("count", 0) == multi.count(g), (pieces, g)
+            if m == 32:  # the stored blocks are normalised there, and a closing pass takes two launches for three shifts
+                assert pa.get("phaseC_multi2", {}).get("count", 0) == 2 * len(multi)
+            if multi and m != 32:
                 # a group of g iterations moves 5 (g - 1) + g + 4 S field passes where g plain ones move g (1 + 4 S)
                 per_pass = pb["phaseC"]["bytes"] / (sum(pieces) * (1 + 4 * S))
                 moved = sum(v["bytes"] for k, v in pa.items() if k.startswith("phaseC"))
