@@ -130,7 +130,7 @@ int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
  * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch -- and, outside capacity mode
  * at m = 8 and 16 with two or more shifts, up to two further residual buffers: the solver updates X_s, P_s of the
  * shifts s >= 1 (inc/block_solvers.hpp:161-181) up to four iterations at a time, which needs the residual block of
- * each deferred iteration (two at a time, as in capacity mode, need none: T doubles as the second buffer).  Results are
+ * each deferred iteration (two at a time, as in capacity mode and at m = 32, need none: T doubles as the second buffer).  Results are
  * bit-identical; a solve that cannot allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation
  * switches the grouping off.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
