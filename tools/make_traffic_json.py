@@ -9,11 +9,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
-NAMES = [(r"k_phaseC_multi<\d+, \d+, 2>", "phaseC_multi2"), (r"k_phaseC_multi<\d+, \d+, 3>", "phaseC_multi3"),
-         (r"k_phaseC_multi<\d+, \d+, 4>", "phaseC_multi4"), (r"k_phaseC<", "phaseC"), (r"k_phaseB", "phaseB"), (r"k_hop4b<\d+, 0, false", "hop"), (r"k_hop4b<\d+, 1, true", "hop_shifted_gram"),
+NAMES = [(r"k_phaseC_multi<\d+, \d+, 2[,>]", "phaseC_multi2"), (r"k_phaseC_multi<\d+, \d+, 3[,>]", "phaseC_multi3"),
+         (r"k_phaseC_multi<\d+, \d+, 4[,>]", "phaseC_multi4"), (r"k_phaseC<", "phaseC"), (r"k_phaseB", "phaseB"), (r"k_hop4b<\d+, 0, false", "hop"), (r"k_hop4b<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4b<\d+, 1, false", "hop_shifted"), (r"k_hop4c<\d+, 0, false", "hop"), (r"k_hop4c<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4c<\d+, 1, false", "hop_shifted"), (r"k_hop4<\d+, 0, false", "hop"), (r"k_hop4<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4<\d+, 1, false", "hop_shifted"), (r"k_hop_fast<\d+, 0", "hop"), (r"k_hop_fast<\d+, 1, true", "hop_shifted_gram")]
@@ -21,7 +22,8 @@ NAMES = [(r"k_phaseC_multi<\d+, \d+, 2>", "phaseC_multi2"), (r"k_phaseC_multi<\d
 
 def per_kernel(d, counter):
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+    # one pass per directory; gpurun merges every call's files back, so a local copy may hold older passes too: newest only
+    for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue

@@ -17,4 +17,4 @@ PY
 }
 run m8 --steps 50 --warmup 5 --local-dims 32 32 32 32 --m 8 --shifts 1 &&
 run m32 --steps 6 --warmup 2 --config 4 &&
-run cap128 --steps 3 --warmup 1 --local-dims 64 64 64 128 --capacity 32
+run cap128 --steps 4 --warmup 2 --local-dims 64 64 64 128 --capacity 32
