@@ -983,7 +983,8 @@ struct DeferredIteration {
 // The deferred iterations' updates and the current one's (coefficients A0/B0 for shift 0, Anew/Bnew by shift for the rest).
 // rinv_out != nullptr (deferred normalisation, m = 8, 16): the blocks are un-normalised and one launch does everything.
 // nullptr (m = 32): the blocks are stored normalised -- the current one by the ordinary phase C launch that also updates
-// shift 0 -- and the shifts >= 1 follow in launches of as many shifts as have room for their matrices in LDS.
+// shift 0.  Either way a launch takes as many shifts as have room for their matrices in LDS (each launch reads the
+// residual blocks again, and normalises them again if they are stored un-normalised).
 int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bcg_field* Qnew, const CMat& rho_new,
                   bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_new,
                   const std::vector<CMat>& Anew, const std::vector<CMat>& Bnew, CMat* rinv_out) {
@@ -1015,7 +1016,7 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
     }
     entries.push_back(e);
   }
-  const int per_launch = lazy ? 8 : bcg::phaseC_multi_max_entries(m, ns, false);
+  const int per_launch = bcg::phaseC_multi_max_entries(m, ns, lazy);  // m = 16: all of 4 shifts at any depth, 8 at depth 2
   static const char* const names[5] = {"", "", "phaseC_multi2", "phaseC_multi3", "phaseC_multi4"};
   for (size_t e0 = 0; e0 < entries.size(); e0 += per_launch) {
     const int n = static_cast<int>(std::min(entries.size() - e0, static_cast<size_t>(per_launch)));

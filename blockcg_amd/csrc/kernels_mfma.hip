@@ -2630,10 +2630,8 @@ static size_t mat_lds_bytes(int m) {
 }
 bool phaseC_multi_fits(int m, int nsteps, int n_shifts) {
   if (nsteps < 2 || nsteps > 4 || n_shifts < 1 || n_shifts > 8) return false;
-  if (m == 32) return nsteps == 2;  // un-normalised blocks are not kept at m = 32; launches of phaseC_multi_max_entries shifts
-  if (m != 8 && m != 16) return false;
-  const int nmat = nsteps + 2 + 2 * nsteps * (n_shifts - 1);  // shift 0 one step, every other shift all of them
-  return mat_lds_bytes(m) * nmat <= 150 * 1024;
+  if (m == 32) return nsteps == 2;  // un-normalised blocks are not kept at m = 32
+  return m == 8 || m == 16;         // more shifts than one launch has LDS room for: several launches (phaseC_multi_max_entries)
 }
 int phaseC_multi_max_entries(int m, int nsteps, bool normalise) {
   const int per_entry = 2 * nsteps;

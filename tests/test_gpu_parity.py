@@ -719,3 +719,32 @@ def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypa
     a, _, _, _, _ = run(4, 6, True)
     for s in range(len(shifts)):
         assert rel_err(a[s], o["X"][s]) < 1e-10
+
+
+def test_grouped_shift_updates_with_more_shifts_than_one_launch_holds(bc, orc, monkeypatch):
+    """8 shifts at m = 16, groups of four iterations: the 60 coefficient matrices of a closing pass do not fit a CU's LDS, so
+    it takes two launches of four shifts, each reading (and normalising) the four residual blocks again.  Bit-identical to
+    the ungrouped solver; against the oracle."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    m, dims, mass = 16, [16, 4, 4, 8], 0.2
+    shifts = [0.0, 1e-4, 1e-3, 1e-2, 0.05, 0.1, 0.5, 2.0]
+    U = orc.fill_gauge(dims, 81)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 82)
+    outs = {}
+    for pair in (4, 0):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
+        st.iterate(9)
+        st.end()
+        outs[pair] = ([x.download() for x in X], ctx.profile())
+    for s in range(len(shifts)):
+        assert np.array_equal(outs[4][0][s], outs[0][0][s]), s
+    assert outs[4][1]["phaseC_multi4"]["count"] == 4 and "phaseC_multi4" not in outs[0][1]  # two groups of four, two launches each
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=9)
+    for s in range(len(shifts)):
+        assert rel_err(outs[4][0][s], o["X"][s]) < 1e-10
