@@ -187,6 +187,58 @@ def resolve_shape(world, local_dims, capacity):
     return list(local_dims), capacity, ladder
 
 
+
+def roofline_of(prof, local_dims, m, S, capacity, world, traffic_path=None):
+    """The `roofline` object of the bench line: the kernel class with the most time in the timed region (HIP events taken by
+    the library on its stream), priced against the roofline it is closest to -- HBM bytes or fp64 flops.
+    `bytes` / `flops` = the ALGORITHMIC bytes and fp64 flops of the launches timed under a name (accumulated by the library
+    per launch: per-site figures of DESIGN.md section 4 x the sites the launch processes), so split launches (phase C in
+    several launches, capacity-mode windows) are priced right.  Returns None when nothing was profiled."""
+    kernels = {k: v for k, v in prof.items() if not k.startswith("stencil_form_") and v.get("bytes", 0) > 0}
+    if not kernels:
+        return None
+    name = max(kernels, key=lambda k: kernels[k]["ms"])
+    e = kernels[name]
+    avg_ms = e["ms"] / e["count"]
+    kb = e["bytes"] / e["count"]
+    # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes
+    # (tools/profile_round.sh -> profiles/hbm_traffic.json); they are quoted only for the shape they were taken at
+    traffic, traffic_source, stencil_ratio = None, None, None
+    tpath = traffic_path or os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        shape = tj.get("_shape", {})
+        if (shape.get("local_dims") == list(local_dims) and shape.get("m") == m and shape.get("n_shifts") == S
+                and shape.get("capacity", 0) == capacity and world == 1):
+            traffic = tj.get(name, {}).get("bytes_per_launch")
+            traffic_source = f"profiles/hbm_traffic.json ({shape.get('measured', 'separate rocprofv3 --pmc passes')})"
+            sr = {}
+            for kn in ("hop", "hop_shifted_gram"):
+                if kn in tj and kn in kernels:
+                    sr[kn] = tj[kn]["bytes_per_launch"] / (kernels[kn]["bytes"] / kernels[kn]["count"])
+            stencil_ratio = sr or None
+    ach = kb / (avg_ms * 1e-3) / 1e9
+    per_kernel = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for k, v in kernels.items() if v["ms"] > 0}
+    # second roofline: the fp64 flops of the same launches against the chip's fp64 rate (matrix pipe = VALU rate on
+    # gfx950: one v_mfma_f64_16x16x4_f64 per 64 cycles and SIMD, measured by tools/microbench/mfma_f64_rate.hip).
+    # It binds the grouped phase C (k_phaseC_multi), whose fields are read once per several iterations.
+    per_kernel_flop = {k: round(v.get("flops", 0.0) / (v["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+                       for k, v in kernels.items() if v["ms"] > 0}
+    hbm_frac = ach / HBM_PEAK_GBPS
+    tf = e.get("flops", 0.0) / e["count"] / (avg_ms * 1e-3) / 1e12
+    mfma_frac = tf / FP64_PEAK_TFLOPS
+    roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac}
+    if mfma_frac > hbm_frac:  # report the roofline that binds this kernel
+        roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_frac}
+    roof.update({"traffic": traffic, "traffic_source": traffic_source,
+                 "avg_launch_ms": avg_ms, "launches": e["count"], "algorithmic_bytes_per_launch": kb,
+                 "flops_per_launch": e.get("flops", 0.0) / e["count"], "hbm_frac": hbm_frac, "fp64_frac": mfma_frac,
+                 "stencil_traffic_ratio": stencil_ratio, "per_kernel_frac": per_kernel,
+                 "per_kernel_fp64_frac": per_kernel_flop})
+    # algorithmic bytes and flops are lower bounds of the work: a fraction above 1 is an accounting error, not a result
+    assert all(f <= 1.0 for f in per_kernel.values()) and all(f <= 1.0 for f in per_kernel_flop.values()), roof
+    return roof
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,53 +361,7 @@ def main():
         its = K / dt
         bytes_iter_total = ctx.bytes_per_iteration(m, S) * world
         hbm_gbps = bytes_iter_total * its / 1e9
-        # dominant kernel of the timed region, from the HIP-event timings taken inside it
-        roof = None
-        kernels = {k: v for k, v in prof.items() if not k.startswith("stencil_form_") and v.get("bytes", 0) > 0}
-        if kernels:
-            # `bytes` = the ALGORITHMIC bytes of the launches timed under that name (accumulated by the library per launch:
-            # per-site figure of DESIGN.md section 4 x the sites the launch processes), `ms` = HIP events on the context's
-            # stream around them: right for split launches (phase C in two launches, capacity-mode windows) as well
-            name = max(kernels, key=lambda k: kernels[k]["ms"])
-            e = kernels[name]
-            avg_ms = e["ms"] / e["count"]
-            kb = e["bytes"] / e["count"]
-            # HBM bytes per launch from the PMC counters are measured in separate rocprofv3 passes
-            # (tools/profile_round.sh -> profiles/hbm_traffic.json); they are quoted only for the shape they were taken at
-            traffic, traffic_source, stencil_ratio = None, None, None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                shape = tj.get("_shape", {})
-                if (shape.get("local_dims") == list(args.local_dims) and shape.get("m") == m and shape.get("n_shifts") == S
-                        and shape.get("capacity", 0) == args.capacity and world == 1):
-                    traffic = tj.get(name, {}).get("bytes_per_launch")
-                    traffic_source = f"profiles/hbm_traffic.json ({shape.get('measured', 'separate rocprofv3 --pmc passes')})"
-                    sr = {}
-                    for kn in ("hop", "hop_shifted_gram"):
-                        if kn in tj and kn in kernels:
-                            sr[kn] = tj[kn]["bytes_per_launch"] / (kernels[kn]["bytes"] / kernels[kn]["count"])
-                    stencil_ratio = sr or None
-            ach = kb / (avg_ms * 1e-3) / 1e9
-            per_kernel = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) for k, v in kernels.items() if v["ms"] > 0}
-            # second roofline: the fp64 flops of the same launches against the chip's fp64 rate (matrix pipe = VALU rate on
-            # gfx950: one v_mfma_f64_16x16x4_f64 per 64 cycles and SIMD, measured by tools/microbench/mfma_f64_rate.hip).
-            # It binds the grouped phase C (k_phaseC_multi), whose fields are read once per several iterations.
-            per_kernel_flop = {k: round(v.get("flops", 0.0) / (v["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
-                               for k, v in kernels.items() if v["ms"] > 0}
-            hbm_frac = ach / HBM_PEAK_GBPS
-            tf = e.get("flops", 0.0) / e["count"] / (avg_ms * 1e-3) / 1e12
-            mfma_frac = tf / FP64_PEAK_TFLOPS
-            roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac}
-            if mfma_frac > hbm_frac:  # report the roofline that binds this kernel
-                roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_frac}
-            roof.update({"traffic": traffic, "traffic_source": traffic_source,
-                         "avg_launch_ms": avg_ms, "launches": e["count"], "algorithmic_bytes_per_launch": kb,
-                         "flops_per_launch": e.get("flops", 0.0) / e["count"], "hbm_frac": hbm_frac, "fp64_frac": mfma_frac,
-                         "stencil_traffic_ratio": stencil_ratio, "per_kernel_frac": per_kernel,
-                         "per_kernel_fp64_frac": per_kernel_flop})
-            # algorithmic bytes and flops are lower bounds of the work: a fraction above 1 is an accounting error, not a result
-            assert all(f <= 1.0 for f in per_kernel.values()) and all(f <= 1.0 for f in per_kernel_flop.values()), roof
+        roof = roofline_of(prof, list(args.local_dims), m, S, args.capacity, world)
         out = {
             "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
             "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

@@ -66,3 +66,45 @@ def test_bare_multi_gpu_command_kills_hung_ranks():
     time.sleep(0.5)
     alive = [p for p in started if os.path.exists(f"/proc/{p}") and "Z" not in open(f"/proc/{p}/stat").read().split(")")[-1].split()[0]]
     assert not alive, alive
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_roofline_picks_the_bound_that_binds_the_dominant_kernel(tmp_path):
+    """bench.roofline_of: the kernel class with the most time, priced against HBM bytes or fp64 flops, whichever fraction is
+    larger; PMC traffic is quoted only for the shape it was measured at; a fraction above 1 is an accounting error."""
+    import json
+    import pytest
+    bench = _bench_module()
+    prof = {
+        "hop": {"ms": 100.0, "count": 10, "bytes": 10 * 35.4e9, "flops": 10 * 0.15e12},
+        "phaseC_multi4": {"ms": 175.0, "count": 3, "bytes": 3 * 257.7e9, "flops": 3 * 3.09e12},
+        "stencil_form_k_hop4b": {"ms": 0.0, "count": 10, "bytes": 0.0},
+        "halo_exchange": {"ms": 5.0, "count": 10, "bytes": 0.0},
+    }
+    tj = tmp_path / "traffic.json"
+    tj.write_text(json.dumps({"phaseC_multi4": {"bytes_per_launch": 257.7e9}, "hop": {"bytes_per_launch": 46.8e9},
+                              "_shape": {"local_dims": [64] * 4, "m": 16, "n_shifts": 4, "capacity": 0}}))
+    r = bench.roofline_of(prof, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj))
+    assert r["kernel"] == "phaseC_multi4" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == bench.FP64_PEAK_TFLOPS
+    assert r["achieved"] == pytest.approx(3.09e12 / (175.0 / 3 * 1e-3) / 1e12) and r["frac"] == pytest.approx(r["achieved"] / 78.6)
+    assert r["hbm_frac"] == pytest.approx(257.7e9 / (175.0 / 3 * 1e-3) / 1e9 / 8000.0) and r["hbm_frac"] < r["frac"]
+    assert r["traffic"] == 257.7e9 and r["stencil_traffic_ratio"]["hop"] == pytest.approx(46.8 / 35.4)
+    assert set(r["per_kernel_frac"]) == {"hop", "phaseC_multi4"}  # entries without bytes are not kernels
+    # another shape: the counters are not quoted
+    assert bench.roofline_of(prof, [64, 64, 64, 128], 16, 4, 32, 1, traffic_path=str(tj))["traffic"] is None
+    # a memory-bound dominant kernel is priced against HBM
+    prof["phaseC_multi4"] = {"ms": 58.0, "count": 1, "bytes": 257.7e9, "flops": 3.09e12}
+    r = bench.roofline_of(prof, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj))
+    assert r["kernel"] == "hop" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(35.4e9 / 10e-3 / 1e9 / 8000.0)
+    # more bytes than the peak could move in the measured time: refused
+    prof["hop"]["bytes"] = 10 * 90e9
+    with pytest.raises(AssertionError):
+        bench.roofline_of(prof, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj))
+    assert bench.roofline_of({}, [64] * 4, 16, 4, 0, 1) is None
