@@ -2201,10 +2201,15 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         }
       }
       BCG_STAMPB(0)   // pacing wait of thread 0 (the other waves' share of it shows up in the barrier)
+#if !(defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 64))  // timing experiment: no barrier per step
       __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
+#endif
       BCG_STAMPB(1)   // barrier
       if (x3 + 1 < x3_end) {
         if (CB) dma_links_cb(x3 + 1);
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 16)  // timing experiment: no link DMAs in the steps
+        else if (SHARE) {}
+#endif
         else if (SHARE) dma_links(x3 + 1, false);   // into the other image, in front of this step's ordinary loads
         else fetch_links(x3 + 1, false);       // parked at the end of this step
       }
@@ -2258,10 +2263,15 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       } else {
         const char* const q_o1 = row_o(k_o1, a_o1, s_o1, x3, slot);
         const char* const q_o2 = row_o(k_o2, a_o2, s_o2, x3, slot);
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 4)  // timing experiment: no loads of the rows that leave the bundle
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o1[c] = o2[c] = make_double2(c0 + reinterpret_cast<uintptr_t>(q_o1) * 1e-30, c0 + reinterpret_cast<uintptr_t>(q_o2) * 1e-30);
+#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q_o1, voff, c * M * 16);
 #pragma unroll
         for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
+#endif
       }
       dv2 hv[3];
       if (!ROWDMA) {
@@ -2270,11 +2280,19 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         const char* hal;
         slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
         row_ptrs(kind, xs, gx3, own, hal);
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 8)  // timing experiment: no load of the +x3 row and its halo sites
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          f[3][c] = make_double2(c0 + reinterpret_cast<uintptr_t>(own) * 1e-30, c0);
+          hv[c] = dv2{c0 + reinterpret_cast<uintptr_t>(hal) * 1e-30, c0};
+        }
+#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) f[3][c] = ld_sv(own, voff, c * M * 16);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           if (halo_lane) hv[c] = *reinterpret_cast<const dv2*>(hal + c * M * 16);
+#endif
       }
       const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
       const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
@@ -2342,10 +2360,18 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 2)  // ... no link reads at all: a value the compiler cannot fold
+            const dv2 u = dv2{c0 + k, c0 - r};
+#else
             const dv2 u = uf[k * 3 + r];
+#endif
             t[r].x = fma(u.x, f[mu][k].x, t[r].x); t[r].x = fma(-u.y, f[mu][k].y, t[r].x);
             t[r].y = fma(u.x, f[mu][k].y, t[r].y); t[r].y = fma(u.y, f[mu][k].x, t[r].y);
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 1)  // timing experiment (wrong results): half the link reads from LDS
+            const dv2 v = u;
+#else
             const dv2 v = ub[r * 3 + k];
+#endif
             t[r].x = fma(-v.x, bk[mu][k].x, t[r].x); t[r].x = fma(-v.y, bk[mu][k].y, t[r].x);
             t[r].y = fma(-v.x, bk[mu][k].y, t[r].y); t[r].y = fma(v.y, bk[mu][k].x, t[r].y);
           }
@@ -2394,7 +2420,11 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
         if (RESID) tv[r] = make_double2(tv[r].x - bv[r].x, tv[r].y - bv[r].y);  // AX -= B (test/solvers.cpp:109)
         else if (BCG_HOP4B_STORE_SC1) st_sc1(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 32)  // timing experiment: no output stores
+        else if (tv[r].x == 1.2345e300) st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+#else
         else st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+#endif
       }
       if (GRAM) {
 #pragma unroll
