@@ -52,6 +52,9 @@ typedef __attribute__((address_space(3))) char lds_char_t;
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_char_t*)p));
 }
+#ifndef BCG_HOP4B_INCR
+#define BCG_HOP4B_INCR 1  // carry the step's addresses along a column instead of recomputing them (0: tuning / A-B build)
+#endif
 #ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
 #define BCG_HOP4B_ROWDMA 0
 #endif
@@ -2040,6 +2043,24 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           if (lane + 64 * k < SPW * 9) glds16_link(q3 + BO_SEL(k_b3, k), img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
       }
     };
+    // the same (first = false) from addresses the caller carries along the column instead of recomputing them (INCR below)
+    auto dma_links_at = [&](int x3, const char* fsrc, const char* lsrc, const char* q1, const char* q2) __attribute__((always_inline)) {
+      const unsigned img = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave)));
+#pragma unroll
+      for (int k = 0; k < RFW; ++k)
+        if (lane + 64 * k < SPW * 36) glds16_link(fsrc + fo + k * 1024, img + (36 + 64 * k) * 16);
+      if (lane < 9) glds16_link(lsrc + fo, img);
+      if (!e1) {
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) glds16_link(q1 + BO_SEL(k_b1, k), img + (NFW + 64 * k) * 16);
+      }
+      if (!e2) {
+#pragma unroll
+        for (int k = 0; k < RBK; ++k)
+          if (lane + 64 * k < SPW * 9) glds16_link(q2 + BO_SEL(k_b2, k), img + (NFW + SPW * 9 + 64 * k) * 16);
+      }
+    };
     // CB: the links of the wave's SPW output sites of slice x3 -- every other site of a full-lattice row -- by LDS-DMA into
     // image(x3): forward links (one 36-entry record per site, the records 2 apart), then the backward links of all four
     // directions, each U_mu of the full-lattice site x - mu (periodic; the lattice is undivided).
@@ -2169,6 +2190,61 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       return k_o ? ghb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(x3v) * s_o) * RB
                  : inb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(RING_IN ? slotv : x3v) * s_o) * RB;
     };
+    // INCR: every address a step needs is linear in x3 along a column (whole-lattice addressing, no ring, no checkerboard):
+    // the link rows of slice x3 + 1, the +x3 row with its halo sites (until the column's last slice, which wraps or is a
+    // ghost face), the two rows that leave the bundle, p and out.  They are set up once per column and advanced by their
+    // strides; recomputing them cost ~250 scalar instructions (64-bit multiplies, wave-uniform branches, SGPR reloads) per
+    // step, as many as the step has FMAs.
+    // In capacity mode the ring-addressed side (the output of the plain hop, the input rows of the shifted one) keeps the
+    // closed form; links, p and the other side are carried.
+    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB && !ROWDMA && !PREO;
+    constexpr bool INCR_IN = INCR && !RING_IN, INCR_OUT = INCR && !RING_OUT;
+    const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
+    const char* ik_f = nullptr; const char* ik_l = nullptr; const char* ik_1 = nullptr; const char* ik_2 = nullptr;
+    const char* ir_own = nullptr; const char* ir_lft = nullptr; const char* ir_rgt = nullptr;
+    const char* io_1 = nullptr; const char* io_2 = nullptr; const char* ip_p = nullptr; char* ip_o = nullptr;
+    int64_t id_l = 0, id_1 = 0, id_2 = 0, id_lft = 0, id_rgt = 0, id_o1 = 0, id_o2 = 0;
+#ifdef BCG_HOP4B_INCR_CHECK
+    bool incr_bad = false;
+#endif
+    if (INCR) {
+      const int lo = win.x3_lo, xn = lo + 1;
+      const char* const ub_ = reinterpret_cast<const char*>(U);
+      const char* const ug_ = reinterpret_cast<const char*>(Ughost);
+      const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(xn) * S3;
+      const int64_t f0i = x1 + L1 * (x2 + static_cast<int64_t>(L2) * xn);
+      const int64_t face = static_cast<int64_t>(L1) * L2;
+      ik_f = ub_ + sw0 * (36 * 16);
+      if (!row_start) { ik_l = ik_f - 36 * 16; id_l = id_f; }
+      else if (!sp0) { ik_l = ik_f + static_cast<int64_t>(L0 - 1) * (36 * 16); id_l = id_f; }
+      else { ik_l = ug_ + (static_cast<int64_t>(gm0) + f0i) * (9 * 16); id_l = face * (9 * 16); }
+      {
+        const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(xn) * s_b1;
+        ik_1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
+        id_1 = static_cast<int64_t>(s_b1) * (k_b1 ? 9 * 16 : 36 * 16);
+        const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(xn) * s_b2;
+        ik_2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
+        id_2 = static_cast<int64_t>(s_b2) * (k_b2 ? 9 * 16 : 36 * 16);
+      }
+      if (INCR_IN) ir_own = inb + sw0 * RB;
+      if (!INCR_IN) {}
+      else if (!row_start) { ir_lft = ir_own - RB; id_lft = id_row; }
+      else if (!sp0) { ir_lft = ir_own + static_cast<int64_t>(L0 - 1) * RB; id_lft = id_row; }
+      else { ir_lft = ghb + (static_cast<int64_t>(gm0) + f0i) * RB; id_lft = face * RB; }
+      if (!INCR_IN) {}
+      else if (!row_end) { ir_rgt = ir_own + static_cast<int64_t>(SPW) * RB; id_rgt = id_row; }
+      else if (!sp0) { ir_rgt = ir_own - static_cast<int64_t>(L0 - SPW) * RB; id_rgt = id_row; }
+      else { ir_rgt = ghb + (static_cast<int64_t>(gp0) + f0i) * RB; id_rgt = face * RB; }
+      if (INCR_IN) {
+        io_1 = row_o(k_o1, a_o1, s_o1, lo, 0);
+        io_2 = row_o(k_o2, a_o2, s_o2, lo, 0);
+      }
+      id_o1 = static_cast<int64_t>(s_o1) * RB;
+      id_o2 = static_cast<int64_t>(s_o2) * RB;
+      const int64_t c0s = (static_cast<int64_t>(col) + static_cast<int64_t>(lo) * S3) * RB;
+      ip_p = reinterpret_cast<const char*>(p) + c0s;
+      if (INCR_OUT) ip_o = reinterpret_cast<char*>(out) + c0s;
+    }
     double2 o1[3], o2[3];
     dv2 p1[3], p2[3];  // PREO: the rows of the NEXT step, loaded behind hipcc's back (ld_sv_async) and waited for by hand
     if (PREO) {  // the first step's rows; every later step finds them loaded by the step before
@@ -2210,6 +2286,29 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 16)  // timing experiment: no link DMAs in the steps
         else if (SHARE) {}
 #endif
+        else if (SHARE && INCR) {
+#ifdef BCG_HOP4B_INCR_CHECK  // test build: the carried addresses against the closed forms; a mismatch poisons the output
+          {
+            const int xn = x3 + 1;
+            const char* const ub_ = reinterpret_cast<const char*>(U);
+            const char* const ug_ = reinterpret_cast<const char*>(Ughost);
+            const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(xn) * S3;
+            const char* const cf = ub_ + sw0 * (36 * 16);
+            const char* cl;
+            if (!row_start) cl = ub_ + (sw0 - 1) * (36 * 16);
+            else if (!sp0) cl = ub_ + (sw0 + L0 - 1) * (36 * 16);
+            else cl = ug_ + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + L2 * xn))) * (9 * 16);
+            const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(xn) * s_b1;
+            const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(xn) * s_b2;
+            const char* const c1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
+            const char* const c2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
+            if (cf != ik_f || cl != ik_l || (!e1 && c1 != ik_1) || (!e2 && c2 != ik_2)) incr_bad = true;
+            ik_f = cf; ik_l = cl; ik_1 = c1; ik_2 = c2;
+          }
+#endif
+          dma_links_at(x3 + 1, ik_f, ik_l, ik_1, ik_2);
+          ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;
+        }
         else if (SHARE) dma_links(x3 + 1, false);   // into the other image, in front of this step's ordinary loads
         else fetch_links(x3 + 1, false);       // parked at the end of this step
       }
@@ -2261,8 +2360,17 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           p2[2] = ld_sv_async<2 * M * 16>(q2, voff);
         }
       } else {
-        const char* const q_o1 = row_o(k_o1, a_o1, s_o1, x3, slot);
-        const char* const q_o2 = row_o(k_o2, a_o2, s_o2, x3, slot);
+#ifdef BCG_HOP4B_INCR_CHECK
+        if (INCR_IN) {
+          const char* const c1 = row_o(k_o1, a_o1, s_o1, x3, slot);
+          const char* const c2 = row_o(k_o2, a_o2, s_o2, x3, slot);
+          if (c1 != io_1 || c2 != io_2) incr_bad = true;
+          io_1 = c1; io_2 = c2;
+        }
+#endif
+        const char* const q_o1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3, slot);
+        const char* const q_o2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3, slot);
+        if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 4)  // timing experiment: no loads of the rows that leave the bundle
 #pragma unroll
         for (int c = 0; c < 3; ++c) o1[c] = o2[c] = make_double2(c0 + reinterpret_cast<uintptr_t>(q_o1) * 1e-30, c0 + reinterpret_cast<uintptr_t>(q_o2) * 1e-30);
@@ -2278,8 +2386,24 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         int kind, xs, gx3;
         const char* own;
         const char* hal;
-        slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
-        row_ptrs(kind, xs, gx3, own, hal);
+        if (INCR_IN && x3 + 1 < L3) {  // a slice of `in`: carried along; the column's last +x3 row wraps or is a ghost face
+#ifdef BCG_HOP4B_INCR_CHECK
+          {
+            const char* co_;
+            const char* cl_;
+            const char* cr_;
+            row_ptrs3(0, x3 + 1, x3 + 1, co_, cl_, cr_);
+            if (co_ != ir_own || cl_ != ir_lft || cr_ != ir_rgt) incr_bad = true;
+            ir_own = co_; ir_lft = cl_; ir_rgt = cr_;
+          }
+#endif
+          own = ir_own;
+          hal = (hs ? ir_rgt : ir_lft) + hj * 16;
+          ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
+        } else {
+          slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
+          row_ptrs(kind, xs, gx3, own, hal);
+        }
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 8)  // timing experiment: no load of the +x3 row and its halo sites
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -2295,8 +2419,18 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #endif
       }
       const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
-      const char* const prow = reinterpret_cast<const char*>(p) + crow_site * RB;
-      char* const orow = reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
+#ifdef BCG_HOP4B_INCR_CHECK
+      if (INCR) {
+        if (ip_p != reinterpret_cast<const char*>(p) + crow_site * RB) incr_bad = true;
+        if (INCR_OUT && ip_o != reinterpret_cast<char*>(out) + crow_site * RB) incr_bad = true;
+        ip_p = reinterpret_cast<const char*>(p) + crow_site * RB;
+        if (INCR_OUT) ip_o = reinterpret_cast<char*>(out) + crow_site * RB;
+      }
+#endif
+      const char* const prow = INCR ? ip_p : reinterpret_cast<const char*>(p) + crow_site * RB;
+      char* const orow = INCR_OUT ? ip_o : reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
+      if (INCR) ip_p += id_row;
+      if (INCR_OUT) ip_o += id_row;
       double2 pv[3], bv[3];
       if (MODE != HOP_PLAIN) {
 #pragma unroll
@@ -2418,6 +2552,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       for (int r = 0; r < 3; ++r) {
         if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
+#ifdef BCG_HOP4B_INCR_CHECK
+        if (incr_bad) tv[r] = make_double2(__builtin_nan(""), __builtin_nan(""));
+#endif
         if (RESID) tv[r] = make_double2(tv[r].x - bv[r].x, tv[r].y - bv[r].y);  // AX -= B (test/solvers.cpp:109)
         else if (BCG_HOP4B_STORE_SC1) st_sc1(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 32)  // timing experiment: no output stores
