@@ -55,6 +55,11 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #ifndef BCG_HOP4B_INCR
 #define BCG_HOP4B_INCR 1  // carry the step's addresses along a column instead of recomputing them (0: tuning / A-B build)
 #endif
+#ifndef BCG_HOP4B_INCR_WRAP
+#define BCG_HOP4B_INCR_WRAP 1  // ... the wrap row of a column's last slice too: 0 never (closed form inside the sweep), 2 always,
+                               // 1 where measured faster -- plain hop 10.05-10.23 vs 10.31-10.49 ms, with the fused Gram
+                               // product 12.05-12.37 vs 11.90-12.16 (profiles/r03_stencil_incremental_addresses.txt)
+#endif
 #ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
 #define BCG_HOP4B_ROWDMA 0
 #endif
@@ -2202,6 +2207,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
     const char* ik_f = nullptr; const char* ik_l = nullptr; const char* ik_1 = nullptr; const char* ik_2 = nullptr;
     const char* ir_own = nullptr; const char* ir_lft = nullptr; const char* ir_rgt = nullptr;
+    const char* iw_own = nullptr; const char* iw_lft = nullptr; const char* iw_rgt = nullptr;
     const char* io_1 = nullptr; const char* io_2 = nullptr; const char* ip_p = nullptr; char* ip_o = nullptr;
     int64_t id_l = 0, id_1 = 0, id_2 = 0, id_lft = 0, id_rgt = 0, id_o1 = 0, id_o2 = 0;
 #ifdef BCG_HOP4B_INCR_CHECK
@@ -2235,6 +2241,11 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       else if (!row_end) { ir_rgt = ir_own + static_cast<int64_t>(SPW) * RB; id_rgt = id_row; }
       else if (!sp0) { ir_rgt = ir_own - static_cast<int64_t>(L0 - SPW) * RB; id_rgt = id_row; }
       else { ir_rgt = ghb + (static_cast<int64_t>(gp0) + f0i) * RB; id_rgt = face * RB; }
+      if (INCR_IN) {  // the +x3 row of the column's last slice (slice 0 again, or the +x3 ghost face): set up here so that the
+        int kind, xs, gx3;  // sweep itself holds none of the lattice's extents, splits and ghost offsets
+        slice_of(L3, 0, kind, xs, gx3);
+        row_ptrs3(kind, xs, gx3, iw_own, iw_lft, iw_rgt);
+      }
       if (INCR_IN) {
         io_1 = row_o(k_o1, a_o1, s_o1, lo, 0);
         io_2 = row_o(k_o2, a_o2, s_o2, lo, 0);
@@ -2400,6 +2411,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           own = ir_own;
           hal = (hs ? ir_rgt : ir_lft) + hj * 16;
           ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
+        } else if (INCR_IN && (BCG_HOP4B_INCR_WRAP == 1 ? !GRAM : BCG_HOP4B_INCR_WRAP != 0)) {
+          own = iw_own;
+          hal = (hs ? iw_rgt : iw_lft) + hj * 16;
         } else {
           slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
           row_ptrs(kind, xs, gx3, own, hal);
