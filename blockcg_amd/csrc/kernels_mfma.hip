@@ -60,6 +60,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
                                // 1 where measured faster -- plain hop 10.05-10.23 vs 10.31-10.49 ms, with the fused Gram
                                // product 12.05-12.37 vs 11.90-12.16 (profiles/r03_stencil_incremental_addresses.txt)
 #endif
+// -DBCG_HOP4B_INCR_CHECK: test build -- every carried address is compared with its closed form at every step and a mismatch
+// poisons the output (the closed form is what is used).  -DBCG_HOP4B_EXPERIMENT=<bits>: timing builds that leave parts of a
+// step out and compute WRONG results on purpose (profiles/r03_stencil_ablation.txt); never linked into the product library.
 #ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
 #define BCG_HOP4B_ROWDMA 0
 #endif
