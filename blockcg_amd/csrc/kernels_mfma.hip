@@ -733,7 +733,8 @@ struct MultiSteps {
 };
 // Blocks: one per CU whatever the matrices take of its LDS.  m = 16: 8 waves, 2 per SIMD -- NS residual tiles, the
 // entry's and the next entry's P and X tiles, two accumulators and the LDS operands in flight are 180 .. 250 registers
-// (12 waves at 168 registers spilled and were 1-2 % slower at NS = 2: 56.7 against 55.5-56.1 ms per iteration).  With the
+// (12 waves at 168 registers spilled and were 1-2 % slower at NS = 2: 56.7 against 55.5-56.1 ms per iteration; with the
+// unpredicated body below NS = 2 needs 152 and 12 waves fit, but run the same: 39.8 vs 40.0 ms at the 64^3 x 128 share).  With the
 // fields read once per NS iterations the kernel is bound by the fp64 matrix pipe as much as by HBM (NS = 4, 4 shifts:
 // 54 TFLOP/s of the 78.6 this chip issues, tools/microbench/mfma_f64_rate.hip, next to 4.5 TB/s).
 // NORM = false (m = 32, where the residual block is stored normalised): the Q_j are used as they are and mats holds no
@@ -2865,9 +2866,7 @@ void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const d
   if (m == 8) {
     if (nsteps == 2) BCG_MULTI(8, 12, 2, true, true) else if (nsteps == 3) BCG_MULTI(8, 12, 3, true, true) else BCG_MULTI(8, 12, 4, true, true)
   } else if (m == 16) {
-    static const int nw2 = std::getenv("BCG_PHASEC_MULTI_NW") ? std::atoi(std::getenv("BCG_PHASEC_MULTI_NW")) : 8;
-    if (nsteps == 2 && nw2 == 12) BCG_MULTI(16, 12, 2, true, true)
-    else if (nsteps == 2) BCG_MULTI(16, 8, 2, true, true) else if (nsteps == 3) BCG_MULTI(16, 8, 3, true, true) else BCG_MULTI(16, 8, 4, true, true)
+    if (nsteps == 2) BCG_MULTI(16, 8, 2, true, true) else if (nsteps == 3) BCG_MULTI(16, 8, 3, true, true) else BCG_MULTI(16, 8, 4, true, true)
   } else {
     BCG_MULTI(32, 8, 2, false, false)
   }
