@@ -2486,19 +2486,37 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         f[0][c] = make_double2(a.x, a.y);
         bk[0][c] = make_double2(b.x, b.y);
       }
-      if (e1) {  // forward row of direction 1 leaves the bundle, backward is the partner's
+      // Directions 1, 2: one neighbour is the partner wave's row (LDS), the other the row that leaves the bundle (o1 / o2);
+      // which is forward depends on the wave (e1, e2).  The two cases are two calls of the direction's arithmetic below,
+      // not a per-lane select of 24 registers per step (the compiler turned the former `f[1][c] = e1 ? o1[c] : partner`
+      // into 48 v_cndmask per step: e1 is wave-uniform, but a select was cheaper than a branch around three moves).
+      // Measured (profiles/r03_stencil_incremental_addresses.txt): plain hop 10.1 -> 9.6 ms; the form with the fused Gram
+      // product, whose scalar registers are tighter, 11.7 -> 12.7 with it (100 more SGPR reloads per step), so that form
+      // keeps the selects.
+      constexpr bool DIRBRANCH = !GRAM;
+      double2 lp1[3], lp2[3];
+      if (DIRBRANCH) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = o1[c]; bk[1][c] = make_double2(v.x, v.y); }
+        for (int c = 0; c < 3; ++c) {
+          const dv2 v1 = Cp1[co + c * M], v2 = Cp2[co + c * M];
+          lp1[c] = make_double2(v1.x, v1.y);
+          lp2[c] = make_double2(v2.x, v2.y);
+        }
       } else {
+        if (e1) {  // forward row of direction 1 leaves the bundle, backward is the partner's
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = make_double2(v.x, v.y); bk[1][c] = o1[c]; }
-      }
-      if (e2) {
+          for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = o1[c]; bk[1][c] = make_double2(v.x, v.y); }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = o2[c]; bk[2][c] = make_double2(v.x, v.y); }
-      } else {
+          for (int c = 0; c < 3; ++c) { const dv2 v = Cp1[co + c * M]; f[1][c] = make_double2(v.x, v.y); bk[1][c] = o1[c]; }
+        }
+        if (e2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = make_double2(v.x, v.y); bk[2][c] = o2[c]; }
+          for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = o2[c]; bk[2][c] = make_double2(v.x, v.y); }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { const dv2 v = Cp2[co + c * M]; f[2][c] = make_double2(v.x, v.y); bk[2][c] = o2[c]; }
+        }
       }
       double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
       const int x0 = CB ? 2 * (x0b + sw) + rr : x0b + sw;
@@ -2523,32 +2541,51 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         const dv2* uf = Lf + (sw + 1) * 36 + mu * 9;
         const dv2* ub = mu == 0 ? (CB ? Lb + (3 * SPW + sw) * 9 : Lf + sw * 36)
                                 : (mu == 1 ? ub1 : (mu == 2 ? ub2 : Lb + (2 * SPW + sw) * 9));
-        double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
+        // acc += eta (U_mu(x) F - U_mu(x - mu)^dagger B): F the forward neighbour, B the backward one.  A macro, not a lambda:
+        // with a lambda the form with the fused product reloaded 130 spilled SGPRs per step instead of 40.
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 2)  // ... no link reads at all: a value the compiler cannot fold
-            const dv2 u = dv2{c0 + k, c0 - r};
+#define BCG_LINK_F(k, r) dv2{c0 + k, c0 - r}
 #else
-            const dv2 u = uf[k * 3 + r];
+#define BCG_LINK_F(k, r) uf[(k) * 3 + (r)]
 #endif
-            t[r].x = fma(u.x, f[mu][k].x, t[r].x); t[r].x = fma(-u.y, f[mu][k].y, t[r].x);
-            t[r].y = fma(u.x, f[mu][k].y, t[r].y); t[r].y = fma(u.y, f[mu][k].x, t[r].y);
 #if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 1)  // timing experiment (wrong results): half the link reads from LDS
-            const dv2 v = u;
+#define BCG_LINK_B(k, r, u) (u)
 #else
-            const dv2 v = ub[r * 3 + k];
+#define BCG_LINK_B(k, r, u) ub[(r) * 3 + (k)]
 #endif
-            t[r].x = fma(-v.x, bk[mu][k].x, t[r].x); t[r].x = fma(-v.y, bk[mu][k].y, t[r].x);
-            t[r].y = fma(-v.x, bk[mu][k].y, t[r].y); t[r].y = fma(v.y, bk[mu][k].x, t[r].y);
-          }
+#define BCG_DIR_TERM(F, B)                                                                                   \
+  {                                                                                                          \
+    double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                          \
+      _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                        \
+        const dv2 u = BCG_LINK_F(k, r);                                                                      \
+        t[r].x = fma(u.x, F[k].x, t[r].x); t[r].x = fma(-u.y, F[k].y, t[r].x);                               \
+        t[r].y = fma(u.x, F[k].y, t[r].y); t[r].y = fma(u.y, F[k].x, t[r].y);                                \
+        const dv2 v = BCG_LINK_B(k, r, u);                                                                   \
+        t[r].x = fma(-v.x, B[k].x, t[r].x); t[r].x = fma(-v.y, B[k].y, t[r].x);                              \
+        t[r].y = fma(-v.x, B[k].y, t[r].y); t[r].y = fma(v.y, B[k].x, t[r].y);                               \
+      }                                                                                                      \
+    }                                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+      acc[r].x = fma(eta, t[r].x, acc[r].x);                                                                 \
+      acc[r].y = fma(eta, t[r].y, acc[r].y);                                                                 \
+    }                                                                                                        \
+  }
+        // (the two asm comments differ on purpose: identical tails would be merged again, with selects on the operands)
+#define BCG_KEEP_APART(text) asm volatile("; " text : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y))
+        if (DIRBRANCH && mu == 1) {
+          if (e1) { BCG_DIR_TERM(o1, lp1) BCG_KEEP_APART("direction 1, forward row outside the bundle"); }
+          else { BCG_DIR_TERM(lp1, o1) BCG_KEEP_APART("direction 1, backward row outside the bundle"); }
+        } else if (DIRBRANCH && mu == 2) {
+          if (e2) { BCG_DIR_TERM(o2, lp2) BCG_KEEP_APART("direction 2, forward row outside the bundle"); }
+          else { BCG_DIR_TERM(lp2, o2) BCG_KEEP_APART("direction 2, backward row outside the bundle"); }
+        } else {
+          BCG_DIR_TERM(f[mu], bk[mu])
         }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          acc[r].x = fma(eta, t[r].x, acc[r].x);
-          acc[r].y = fma(eta, t[r].y, acc[r].y);
-        }
+#undef BCG_DIR_TERM
+#undef BCG_LINK_F
+#undef BCG_LINK_B
+#undef BCG_KEEP_APART
         // pin this direction's arithmetic here: the compiler otherwise sinks FMAs past the branches below, towards the
         // stores, and the link entries they read stay live across them
         asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y));
