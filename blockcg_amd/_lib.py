@@ -52,6 +52,8 @@ SIGNATURES = {
     "bcg_capacity_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "bcg_sbcgrq_device_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_size_t)]),
+    "bcg_sbcgrq_plan_bytes": (ctypes.c_int, [ctypes.c_int, c_int_p, c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, c_size_p]),
     "bcg_field_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_field_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_field_width": (ctypes.c_int, [ctypes.c_void_p]),

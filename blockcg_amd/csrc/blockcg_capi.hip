@@ -203,13 +203,8 @@ int upload_mat(bcg_context* c, const CMat& M, const double2** dev_out) {
 
 int ensure_staging(bcg_context* c, size_t bytes) {
   if (bytes <= c->staging_bytes) return BCG_OK;
+  BCG_TRY(stream_sync(c));  // a conversion kernel of an earlier call may still read the old buffer
   if (c->staging) (void)hipFree(c->staging);
-  for (int k = 0; k < 2; ++k) {
-    if (c->xfer_dev[k]) (void)hipFree(c->xfer_dev[k]);
-    if (c->xfer_pin[k]) (void)hipHostFree(c->xfer_pin[k]);
-    if (c->xfer_done[k]) (void)hipEventDestroy(c->xfer_done[k]);
-    if (c->xfer_stream[k]) (void)hipStreamDestroy(c->xfer_stream[k]);
-  }
   c->staging = nullptr;
   c->staging_bytes = 0;
   HIP_TRY(c, hipMalloc(&c->staging, bytes));
@@ -435,6 +430,16 @@ int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, in
 // Capacity mode with overlapped exchanges: the received faces of slice x3 = 0 of every split direction, saved aside
 // (save) or put back (!save).  The ghost ranges of slice 0 are re-used for the faces of `tmp` while the source's faces of
 // that slice are needed once more at the end of the sweep (apply_shifted_ring).
+int ensure_halo_save(bcg_context* c, size_t total) {
+  if (total <= c->halo_save_bytes) return BCG_OK;
+  BCG_TRY(stream_sync(c));
+  if (c->halo_save) (void)hipFree(c->halo_save);
+  c->halo_save = nullptr;
+  c->halo_save_bytes = 0;
+  HIP_TRY(c, hipMalloc(&c->halo_save, total));
+  c->halo_save_bytes = total;
+  return BCG_OK;
+}
 int slice0_faces(bcg_context* c, size_t site_bytes, bool save) {
   int peer_s[8], peer_r[8];
   size_t off_s[8], off_r[8], nb[8];
@@ -442,14 +447,7 @@ int slice0_faces(bcg_context* c, size_t site_bytes, bool save) {
   if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
   size_t total = 0;
   for (int k = 0; k < n; ++k) total += nb[k] / c->lat.L[3];
-  if (total > c->halo_save_bytes) {
-    BCG_TRY(stream_sync(c));
-    if (c->halo_save) (void)hipFree(c->halo_save);
-    c->halo_save = nullptr;
-    c->halo_save_bytes = 0;
-    HIP_TRY(c, hipMalloc(&c->halo_save, total));
-    c->halo_save_bytes = total;
-  }
+  BCG_TRY(ensure_halo_save(c, total));
   size_t at = 0;
   for (int k = 0; k < n; ++k) {
     const size_t each = nb[k] / c->lat.L[3];
@@ -700,29 +698,28 @@ int get_tmp_half(bcg_context* c, int m, int parity, bcg_field** out) {
 //   neighbours, T[lo, hi).  Writing slice s of tmp replaces slice s - R, which no later chunk reads.
 // Slices L3-1 and 0 of tmp are computed twice (2/L3 more work in the first stencil).  The ghost buffer is shared: the faces of
 // tmp[lo, hi) land on the range that held the faces of P[lo, hi), which the first stencil no longer reads -- except
-// slice 0 at the very end, whose P faces are exchanged again.  The exchanges are not overlapped with arithmetic in this mode.
+// slice 0 at the very end, whose P faces are exchanged again (serial form) or restored from a copy (overlapped form, below).
 bool capacity_path(const bcg_context* c, int m) {
   return c->tmp_ring > 0 && fast_hop(c, m) && bcg::hop_can_split_tiles(m, c->lat);
 }
-int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
-                       int* gram_blocks) {
-  const int m = P->m, R = c->tmp_ring, L3 = c->lat.L[3];
-  // Overlapped form (ranks that exchange faces, split callbacks present, ring of at least 2 C + 2 slices): the exchange of
-  // chunk k's tmp faces runs while the first stencil works on chunk k + 1 and the second one on chunk k - 1, so the ring
-  // holds two chunks and the two boundary slices.  Otherwise C = R - 2 and every exchange is waited for where it is posted.
-  const bool overlap = c->ring_overlap && can_overlap(c) && (R - 2) / 2 >= 1;
-  const int C = overlap ? (R - 2) / 2 : R - 2;
-  BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+// chunk length of the capacity-mode sweep and whether its exchanges are overlapped (apply_shifted_ring)
+inline bool ring_overlapped(const bcg_context* c) { return c->ring_overlap && can_overlap(c) && (c->tmp_ring - 2) / 2 >= 1; }
+inline int ring_chunk(const bcg_context* c) {
+  const int most = ring_overlapped(c) ? (c->tmp_ring - 2) / 2 : c->tmp_ring - 2;
+  // BCG_RING_CHUNK (tests, tuning): shorter chunks than the ring allows -- e.g. the overlapped form's 15-slice windows of
+  // ring 32 on a single rank, where the serial form would sweep 30 slices at a time
+  return c->ring_chunk_override > 0 && c->ring_chunk_override < most ? c->ring_chunk_override : most;
+}
+// Everything capacity mode allocates for width m: the ring, the block partials of all chunks side by side (the stencil
+// grid stays the tuned one: a smaller grid loses the x3 walk), the face buffers and the copy of the slice-0 faces.
+int ensure_ring_scratch(bcg_context* c, int m) {
+  const int R = c->tmp_ring, L3 = c->lat.L[3], C = ring_chunk(c);
   double2*& ring = c->tmp_ring_buf[m];
   if (!ring) HIP_TRY(c, hipMalloc(&ring, static_cast<size_t>(R) * c->lat.stride[3] * 3 * m * sizeof(double2)));
-  if (gram_blocks) *gram_blocks = 0;
-  const bool gram = gram_blocks && m == 16;
   BCG_TRY(ensure_scratch(c));
-  // block partials of all chunks side by side (the stencil grid stays the tuned one: a smaller grid loses the x3 walk)
   const int chunks = (L3 + C - 1) / C;
-  const bcg::HopTuning& tune = c->hop_tune;
-  const size_t need = static_cast<size_t>(tune.blocks > 0 ? tune.blocks : kFastBlocks) * chunks * m * m * sizeof(double2);
-  if (gram && need > c->partials_bytes) {
+  const size_t need = static_cast<size_t>(c->hop_tune.blocks > 0 ? c->hop_tune.blocks : kFastBlocks) * chunks * m * m * sizeof(double2);
+  if (m == 16 && need > c->partials_bytes) {
     BCG_TRY(stream_sync(c));
     (void)hipFree(c->partials);
     c->partials = nullptr;
@@ -730,12 +727,33 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     HIP_TRY(c, hipMalloc(&c->partials, need));
     c->partials_bytes = need;
   }
+  if (c->distributed) {
+    const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
+    BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
+    if (ring_overlapped(c)) BCG_TRY(ensure_halo_save(c, static_cast<size_t>(c->ghost_sites) / L3 * site_bytes));
+  }
+  return BCG_OK;
+}
+int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
+                       int* gram_blocks) {
+  const int m = P->m, R = c->tmp_ring, L3 = c->lat.L[3];
+  // Overlapped form (ranks that exchange faces, split callbacks present, ring of at least 2 C + 2 slices): the exchange of
+  // chunk k's tmp faces runs while the first stencil works on chunk k + 1 and the second one on chunk k - 1, so the ring
+  // holds two chunks and the two boundary slices.  Otherwise C = R - 2 and every exchange is waited for where it is posted.
+  const bool overlap = ring_overlapped(c);
+  const int C = ring_chunk(c);
+  BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+  BCG_TRY(ensure_ring_scratch(c, m));
+  double2* const ring = c->tmp_ring_buf[m];
+  if (gram_blocks) *gram_blocks = 0;
+  const bool gram = gram_blocks && m == 16;
+  const bcg::HopTuning& tune = c->hop_tune;
   const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
   BCG_TRY(halo_field(c, P));
   if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/true));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
     note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
-    ProfScope ps(c, "hop_ring", alg_bytes(c, m, 2, 1, n, L3));
+    ProfScope ps(c, "hop_ring", alg_bytes(c, m, 2, 1, n, L3), hop_flops(c, m, false, n, L3));
     const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
                                         0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});
     if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
@@ -745,7 +763,8 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   int total = 0;
   auto second = [&](int lo, int hi) -> int {  // T[lo, hi) from tmp[lo - 1, hi]
     {
-      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring", alg_bytes(c, m, 3, 1, hi - lo, L3));
+      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring", alg_bytes(c, m, 3, 1, hi - lo, L3),
+                   hop_flops(c, m, gram, hi - lo, L3));
       const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                           c0, c->partials + static_cast<size_t>(total) * m * m, gram, kFastBlocks, tune, 0,
                                           bcg::HopWindow{lo, hi - lo, R});
@@ -792,6 +811,18 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     }
   }
   if (gram) *gram_blocks = total;
+  return BCG_OK;
+}
+
+// The device memory apply_shifted needs for operands shaped like `like`, allocated now rather than at the first call
+int reserve_operator_scratch(bcg_context* c, const bcg_field* like) {
+  const int m = like->m;
+  bcg_field* tmp;
+  if (like->parity >= 0) return get_tmp_half(c, m, 1 - like->parity, &tmp);
+  if (fast_hop(c, m)) BCG_TRY(ensure_scratch(c));
+  if (capacity_path(c, m)) return ensure_ring_scratch(c, m);
+  BCG_TRY(get_tmp(c, m, &tmp));
+  if (c->distributed) BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * 3 * m * sizeof(double2)));
   return BCG_OK;
 }
 
@@ -985,12 +1016,14 @@ struct DeferredIteration {
 // nullptr (m = 32): the blocks are stored normalised -- the current one by the ordinary phase C launch that also updates
 // shift 0.  Either way a launch takes as many shifts as have room for their matrices in LDS (each launch reads the
 // residual blocks again, and normalises them again if they are stored un-normalised).
+// flush_rinv != nullptr: the "current" iteration is itself a deferred one whose shift 0 has been updated already (error
+// paths, sbcgrq_flush_pending): only the shifts >= 1 are touched, *flush_rinv is its rho^-1 and rho_new, A0, B0 are unused.
 int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bcg_field* Qnew, const CMat& rho_new,
                   bcg_field* const* X, bcg_field* const* P, const CMat& A0, const CMat& B0, int n_active_new,
-                  const std::vector<CMat>& Anew, const std::vector<CMat>& Bnew, CMat* rinv_out) {
+                  const std::vector<CMat>& Anew, const std::vector<CMat>& Bnew, CMat* rinv_out, bool lazy,
+                  const CMat* flush_rinv = nullptr) {
   const int m = Qnew->m, ns = static_cast<int>(pend.size()) + 1;
-  const bool lazy = rinv_out != nullptr;
-  const CMat rinv_new = bcg::upper_triangular_inverse(rho_new);
+  const CMat rinv_new = flush_rinv ? *flush_rinv : (lazy ? bcg::upper_triangular_inverse(rho_new) : CMat());
   const double2* Qd[4];
   for (int j = 0; j + 1 < ns; ++j) Qd[j] = pend[j].Q->d;
   Qd[ns - 1] = Qnew->d;
@@ -999,13 +1032,16 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
     std::vector<const CMat*> mats;
   };
   std::vector<Entry> entries;
-  if (lazy) {
+  if (flush_rinv) {
+    // nothing for shift 0
+  } else if (lazy) {
     entries.push_back(Entry{0, ns - 1, ns, {&A0, &B0}});
   } else {
     const std::vector<CMat> a0(1, A0), b0(1, B0);
     BCG_TRY(phase_C(c, Qnew, rho_new, X, P, 1, a0, b0, nullptr));  // Q <- Q rho^-1 stored; shift 0
   }
-  for (int s = 1; s < pend[0].n_active; ++s) {  // the active set only shrinks: a shift takes a prefix of the steps
+  const int n_first = ns > 1 ? pend[0].n_active : n_active_new;
+  for (int s = 1; s < n_first; ++s) {  // the active set only shrinks: a shift takes a prefix of the steps
     Entry e{s, 0, 0, {}};
     for (int j = 0; j < ns; ++j) {
       const bool on = s < (j + 1 < ns ? pend[j].n_active : n_active_new);
@@ -1145,6 +1181,8 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
   if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
+  if (const char* e = std::getenv("BCG_RING_CHUNK")) c->ring_chunk_override = std::atoi(e);
+  if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
@@ -1187,6 +1225,17 @@ int bcg_context_destroy(bcg_context* c) {
   if (c->fold_tickets) (void)hipFree(c->fold_tickets);
   if (c->pin_gram) (void)hipHostFree(c->pin_gram);
   if (c->staging) (void)hipFree(c->staging);
+  for (int k = 0; k < 2; ++k) {  // the upload / download pipeline (ensure_xfer)
+    if (c->xfer_stream[k]) (void)hipStreamSynchronize(c->xfer_stream[k]);
+    if (c->xfer_dev[k]) (void)hipFree(c->xfer_dev[k]);
+    if (c->xfer_pin[k]) (void)hipHostFree(c->xfer_pin[k]);
+    if (c->xfer_done[k]) (void)hipEventDestroy(c->xfer_done[k]);
+    if (c->xfer_stream[k]) (void)hipStreamDestroy(c->xfer_stream[k]);
+    c->xfer_dev[k] = nullptr;
+    c->xfer_pin[k] = nullptr;
+    c->xfer_done[k] = nullptr;
+    c->xfer_stream[k] = nullptr;
+  }
   for (auto& kv : c->prof)
     for (auto& pr : kv.second.pending) {
       (void)hipEventDestroy(pr.first);
@@ -1280,6 +1329,7 @@ int bcg_profile_reset(bcg_context* c) {
     kv.second.ms = 0;
     kv.second.count = 0;
     kv.second.bytes = 0;
+    kv.second.flops = 0;
   }
   return BCG_OK;
 }
@@ -1336,19 +1386,45 @@ int bcg_capacity_mode(bcg_context* c, int ring_slices) {
   return BCG_OK;
 }
 
+// Pure host arithmetic (no context, no device): what one rank of `grid` allocates for an SBCGrQ solve of width m.
+int bcg_sbcgrq_plan_bytes(int ndim, const int* global_dims, const int* grid, int m, int n_shifts, int consume_B, int ring_slices,
+                          int ring_overlapped, int group_depth, size_t* bytes_out) {
+  if (!global_dims || !bytes_out || ndim < 1 || ndim > 4 || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
+  int64_t V = 1, ghost = 0;
+  int L[4] = {1, 1, 1, 1};
+  for (int mu = 0; mu < ndim; ++mu) {
+    const int g = grid ? grid[mu] : 1;
+    if (g < 1 || global_dims[mu] < 1 || global_dims[mu] % g != 0) return BCG_ERR_INVALID;
+    L[mu] = global_dims[mu] / g;
+    V *= L[mu];
+  }
+  for (int mu = 0; mu < ndim; ++mu)
+    if (grid && grid[mu] > 1) ghost += 2 * (V / L[mu]);
+  if (ring_slices != 0 && (ndim != 4 || ring_slices < 3 || L[3] % ring_slices != 0)) return BCG_ERR_INVALID;
+  const size_t field = static_cast<size_t>(V) * 3 * m * sizeof(double2);
+  size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
+  total += field * std::max(0, group_depth - 2);                                          // further residual buffers
+  total += ring_slices > 0 ? field / L[3] * ring_slices : field;                          // tmp of dirac_op::op
+  total += static_cast<size_t>(V) * ndim * 9 * sizeof(double2);                          // links
+  total += static_cast<size_t>(ghost) * (2 * 3 * m + 9) * sizeof(double2);                // send + receive faces, ghost links
+  if (ring_slices > 0 && ring_overlapped) total += static_cast<size_t>(ghost) / L[3] * 3 * m * sizeof(double2);  // saved slice-0 faces
+  size_t partials = static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2);
+  if (ring_slices > 0 && m == 16) {  // capacity mode: the block partials of all chunks side by side (ensure_ring_scratch)
+    const int C = ring_overlapped ? (ring_slices - 2) / 2 : ring_slices - 2;
+    const int chunks = (L[3] + C - 1) / C;
+    partials = std::max(partials, static_cast<size_t>(kFastBlocks) * chunks * m * m * sizeof(double2));
+  }
+  total += partials + kMatSlotBytes * (kMatSlots + 1);
+  *bytes_out = total;
+  return BCG_OK;
+}
+
 int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consume_B, size_t* bytes_out) {
   DeviceScope on_device(c);
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
-  const size_t field = static_cast<size_t>(c->lat.V) * 3 * m * sizeof(double2);
-  size_t total = field * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1));  // X_s, P_s, Q, T (+ B)
-  total += field * std::max(0, pair_shifts_depth(c, m, n_shifts) - 2);                    // further residual buffers
-  total += capacity_path(c, m) ? field / c->lat.L[3] * c->tmp_ring : field;                // tmp of dirac_op::op
-  total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                 // links
-  total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);       // send + receive faces, ghost links
-  if (capacity_path(c, m)) total += static_cast<size_t>(c->ghost_sites) / c->lat.L[3] * 3 * m * sizeof(double2);  // saved slice-0 faces
-  total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
-  *bytes_out = total;
-  return BCG_OK;
+  const bool cap = capacity_path(c, m);
+  return bcg_sbcgrq_plan_bytes(c->ndim, c->gdims, c->grid, m, n_shifts, consume_B, cap ? c->tmp_ring : 0,
+                               cap && c->distributed && ring_overlapped(c) ? 1 : 0, pair_shifts_depth(c, m, n_shifts), bytes_out);
 }
 
 // The same plan for ONE half-volume solve (bcg_field_create_half: every work field holds V/2 sites; links stay full)
@@ -1899,6 +1975,7 @@ struct bcg_sbcgrq_state {
   std::vector<DeferredIteration> pending;
   std::vector<bcg_field*> Qfree;         // residual buffers not in use (depth - 2 of them when nothing is pending)
   int depth = 1;
+  bool failed = false;                   // an iteration returned an error: no further iterations on this state
 };
 
 namespace {
@@ -1947,6 +2024,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
     BCG_TRY(phase_B(c, st->Q, st->T, st->alpha, G2, st->q_lazy ? &st->q_rinv : nullptr));  // global reduction #2
   }
   st->rho_old = st->rho;                                 // :150
+  if (c->debug_fail_iter > 0 && st->iter == c->debug_fail_iter) G2(0, 0) = cd(std::nan(""), 0.0);  // test aid: BCG_DEBUG_FAIL_ITER
   if (!G2.all_finite()) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not finite");
   if (!bcg::cholesky_upper(G2, st->rho)) BCG_FAIL(c, BCG_ERR_NUMERIC, "thinQR: Gram matrix is not positive definite");
   st->delta = st->rho * st->delta;                       // :153
@@ -2011,13 +2089,15 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
     d.B = B_by_shift;
     st->pending.push_back(d);
   } else if (!st->pending.empty()) {
-    BCG_TRY(phase_C_multi(c, st->pending, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag, n_active,
-                          A_by_shift, B_by_shift, lazy ? &st->q_rinv : nullptr));
-    for (const DeferredIteration& d : st->pending) {
+    std::vector<DeferredIteration> pend;
+    pend.swap(st->pending);  // whatever happens below, these updates are not applied a second time (sbcgrq_flush_pending)
+    const int rc = phase_C_multi(c, pend, st->Q, st->rho, st->X.data(), st->P.data(), alpha_delta, rho_dag, n_active,
+                                 A_by_shift, B_by_shift, lazy ? &st->q_rinv : nullptr, lazy);
+    for (const DeferredIteration& d : pend) {
       if (!st->T) st->T = d.Q;
       else st->Qfree.push_back(d.Q);
     }
-    st->pending.clear();
+    BCG_TRY(rc);
   } else {
     BCG_TRY(phase_C(c, st->Q, st->rho, Xa.data(), Pa.data(), static_cast<int>(Xa.size()), Acoef, Bcoef,
                     lazy ? &st->q_rinv : nullptr));
@@ -2025,6 +2105,55 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   st->q_lazy = lazy;  // from now on the stored Q is un-normalised: Q_true = Q q_rinv
   if (tracing) trace->recorded += 1;
   return BCG_OK;
+}
+
+// An iteration failed (thinQR breakdown, a non-finite Gram matrix, a HIP or communication error) while earlier
+// iterations' updates of the shifts >= 1 were still waiting for the pass that closes their group: apply them now, so that
+// the X_s the caller keeps are those of the last completed iteration for every shift, as in the reference, where every
+// shift is current at any point an error could surface (inc/block_solvers.hpp:161-181 run in every iteration).
+int sbcgrq_flush_pending(bcg_sbcgrq_state* st) {
+  if (st->pending.empty()) return BCG_OK;
+  bcg_context* c = st->c;
+  const int m = st->m;
+  std::vector<DeferredIteration> pend;
+  pend.swap(st->pending);
+  const DeferredIteration last = pend.back();
+  pend.pop_back();
+  const bool lazy = lazy_q_width(c, m);
+  int rc = BCG_OK;
+  if (pend.empty()) {  // one iteration: the ordinary phase C kernel over the shifts >= 1, its rho^-1 applied in registers
+    for (int s0 = 1; s0 < last.n_active && rc == BCG_OK;) {
+      const int ns = std::min(bcg::phaseC_max_shifts(m, false), last.n_active - s0);
+      const CMat unused = CMat::identity(m);  // slot 0 is skipped by the kernel when the block is stored normalised
+      std::vector<const CMat*> mats(1, lazy ? &last.rinv : &unused);
+      double2* Xp[8];
+      double2* Pp[8];
+      for (int k = 0; k < ns; ++k) {
+        mats.push_back(&last.A[s0 + k]);
+        mats.push_back(&last.B[s0 + k]);
+        Xp[k] = st->X[s0 + k]->d;
+        Pp[k] = st->P[s0 + k]->d;
+      }
+      const double2* Md;
+      rc = upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md);
+      if (rc != BCG_OK) break;
+      bcg::launch_phaseC(c->stream, m, rows_of(last.Q), last.Q->d, Xp, Pp, ns, Md, lazy ? 2 : 0, c->row_blocks_C);
+      rc = check_launch(c, "phaseC");
+      s0 += ns;
+    }
+  } else {
+    const CMat none;
+    rc = phase_C_multi(c, pend, last.Q, none, st->X.data(), st->P.data(), none, none, last.n_active, last.A, last.B, nullptr,
+                       lazy, &last.rinv);
+  }
+  pend.push_back(last);
+  for (const DeferredIteration& d : pend) {
+    if (d.Q == st->Q || d.Q == st->T) continue;
+    if (!st->T) st->T = d.Q;
+    else st->Qfree.push_back(d.Q);
+  }
+  if (rc == BCG_OK) rc = stream_sync(c);
+  return rc;
 }
 
 }  // namespace
@@ -2086,6 +2215,17 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
 #undef BEGIN_TRY
   st->alpha_s.assign(n_shifts, Identity);  // :122
   st->beta_s.assign(n_shifts, Identity);   // :123
+  // What the first iteration would otherwise allocate lazily (tmp or the ring, face buffers, partials) comes BEFORE the
+  // optional residual buffers: a solve that fits without them must not fail because they took the room (the header's
+  // promise: a solve that cannot allocate them runs at a smaller depth).
+  {
+    int rc_ = reserve_operator_scratch(c, B);
+    if (rc_ != BCG_OK) {
+      sbcgrq_release(st);
+      delete st;
+      return rc_;
+    }
+  }
   st->depth = pair_shifts_depth(c, m, n_shifts);
   for (int k = 2; k < st->depth; ++k) {  // depth 2 needs none (T doubles as the second residual buffer)
     bcg_field* q = nullptr;
@@ -2108,9 +2248,18 @@ int bcg_sbcgrq_iterate(bcg_sbcgrq_state* st, int max_new_iterations, int* iterat
                        bcg_sbcgrq_trace* trace) {
   DeviceScope on_device(st ? st->c : nullptr);
   if (!st) return BCG_ERR_INVALID;
+  if (st->failed) BCG_FAIL(st->c, BCG_ERR_INVALID, "SBCGrQ: an earlier iteration on this state returned an error");
   int done = 0;
   while (st->residual > st->eps && done < max_new_iterations) {  // :132
-    BCG_TRY(sbcgrq_iteration(st, trace, done + 1 < max_new_iterations));
+    const int rc = sbcgrq_iteration(st, trace, done + 1 < max_new_iterations);
+    if (rc != BCG_OK) {
+      st->failed = true;
+      const std::string why = st->c->err;
+      (void)hipGetLastError();
+      if (sbcgrq_flush_pending(st) != BCG_OK) st->c->err = why + " (and the deferred updates of the shifted systems could not be applied)";
+      else st->c->err = why;
+      return rc;
+    }
     ++done;
   }
   BCG_TRY(stream_sync(st->c));

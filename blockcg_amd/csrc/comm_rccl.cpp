@@ -18,7 +18,9 @@ static_assert(BCG_RCCL_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size"
 
 struct bcg_rccl_comm {
   bcg_context* ctx = nullptr;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;       // all-reduce, barrier / max and the blocking exchange: only ever used on ctx_stream
+  ncclComm_t halo_comm = nullptr;  // the split exchange: only ever used on xfer_stream (a communicator of its own, see create)
+  bool halo_comm_own = false;
   int rank = 0, world = 1, device = 0;
   hipStream_t ctx_stream = nullptr;   // the context's stream (not owned)
   hipStream_t xfer_stream = nullptr;  // split exchange: higher priority than the compute stream
@@ -52,7 +54,7 @@ bool fail(bcg_rccl_comm* c, const std::string& msg) {
 // the point-to-point kernels pair up whatever order the peers appear in.  Two messages to the same peer (a direction
 // split over two ranks: the plus and the minus neighbour coincide) are matched by posting order, which is the same
 // ascending-direction, low-face-first order on both sides (bcg_halo_plan).
-int post_group(bcg_rccl_comm* c, hipStream_t stream, int n, const int* peer_send, const int* peer_recv,
+int post_group(bcg_rccl_comm* c, ncclComm_t comm, hipStream_t stream, int n, const int* peer_send, const int* peer_recv,
                const size_t* off_s, const size_t* off_r, const size_t* nbytes) {
   void *send = nullptr, *recv = nullptr;
   size_t each = 0;
@@ -68,10 +70,10 @@ int post_group(bcg_rccl_comm* c, hipStream_t stream, int n, const int* peer_send
   ncclResult_t bad = ncclSuccess;
   const char* what = "";
   for (int k = 0; k < n && bad == ncclSuccess; ++k) {
-    bad = ncclSend(static_cast<const char*>(send) + off_s[k], nbytes[k], ncclChar, peer_send[k], c->comm, stream);
+    bad = ncclSend(static_cast<const char*>(send) + off_s[k], nbytes[k], ncclChar, peer_send[k], comm, stream);
     what = "ncclSend";
     if (bad != ncclSuccess) break;
-    bad = ncclRecv(static_cast<char*>(recv) + off_r[k], nbytes[k], ncclChar, peer_recv[k], c->comm, stream);
+    bad = ncclRecv(static_cast<char*>(recv) + off_r[k], nbytes[k], ncclChar, peer_recv[k], comm, stream);
     what = "ncclRecv";
   }
   // the group is closed on EVERY path: a group left open on this thread would swallow each later RCCL call (the
@@ -84,13 +86,13 @@ int post_group(bcg_rccl_comm* c, hipStream_t stream, int n, const int* peer_send
 
 int cb_halo(void* user, int n, const int* ps, const int* pr, const size_t* os, const size_t* orr, const size_t* nb) {
   bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
-  return post_group(c, c->ctx_stream, n, ps, pr, os, orr, nb);
+  return post_group(c, c->comm, c->ctx_stream, n, ps, pr, os, orr, nb);
 }
 int cb_halo_begin(void* user, int n, const int* ps, const int* pr, const size_t* os, const size_t* orr, const size_t* nb) {
   bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
   HIP_OK(c, hipEventRecord(c->packed, c->ctx_stream));            // the faces are packed once this fires
   HIP_OK(c, hipStreamWaitEvent(c->xfer_stream, c->packed, 0));
-  if (post_group(c, c->xfer_stream, n, ps, pr, os, orr, nb) != 0) return 1;
+  if (post_group(c, c->halo_comm, c->xfer_stream, n, ps, pr, os, orr, nb) != 0) return 1;
   HIP_OK(c, hipEventRecord(c->arrived, c->xfer_stream));
   return 0;
 }
@@ -194,6 +196,23 @@ int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int w
   std::memcpy(&id, id_bytes, sizeof id);
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) return bail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r), BCG_ERR_COMM);
+  // One communicator per stream.  The split exchange lives on xfer_stream while the Gram all-reduce is enqueued on the
+  // context's stream; with ONE communicator RCCL would order the two launches against each other with an event of its
+  // own -- the next chunk's exchange silently queued behind a pending all-reduce, or the reverse.  ncclCommSplit with one
+  // colour duplicates the communicator (collective over all ranks, no second unique id to distribute); every rank takes
+  // the same path, so matching sends and receives always meet on the same communicator.  BCG_RCCL_SINGLE_COMM=1 keeps the
+  // round-3 behaviour (A/B on hardware); a failed split is an error, not a silent fallback.
+  const char* single = std::getenv("BCG_RCCL_SINGLE_COMM");
+  if (single && std::atoi(single) != 0) {
+    c->halo_comm = c->comm;
+  } else {
+    r = ncclCommSplit(c->comm, 0, rank, &c->halo_comm, nullptr);
+    if (r != ncclSuccess) {
+      c->halo_comm = nullptr;
+      return bail(std::string("ncclCommSplit (communicator of the halo stream): ") + ncclGetErrorString(r), BCG_ERR_COMM);
+    }
+    c->halo_comm_own = true;
+  }
   int lo = 0, hi = 0;  // numerically lower = higher priority
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
   if (hipStreamCreateWithPriority(&c->xfer_stream, hipStreamNonBlocking, hi) != hipSuccess ||
@@ -212,6 +231,8 @@ int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int w
 }
 
 const bcg_comm* bcg_comm_rccl_callbacks(const bcg_rccl_comm* c) { return c ? &c->table : nullptr; }
+
+int bcg_comm_rccl_communicators(const bcg_rccl_comm* c) { return !c ? 0 : (c->halo_comm_own ? 2 : 1); }
 
 int bcg_rccl_max_double(bcg_rccl_comm* c, double* v) {
   if (!c || !v) return BCG_ERR_INVALID;
@@ -240,6 +261,7 @@ int bcg_comm_rccl_destroy(bcg_rccl_comm* c) {
   if (c->packed) (void)hipEventDestroy(c->packed);
   if (c->arrived) (void)hipEventDestroy(c->arrived);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->halo_comm_own && c->halo_comm) (void)ncclCommDestroy(c->halo_comm);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
   return BCG_OK;

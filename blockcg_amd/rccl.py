@@ -21,6 +21,7 @@ SIGNATURES = {
     "bcg_comm_rccl_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_void_p)]),
     "bcg_comm_rccl_callbacks": (ctypes.POINTER(_lib.bcg_comm), [ctypes.c_void_p]),
+    "bcg_comm_rccl_communicators": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_barrier": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_max_double": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "bcg_comm_rccl_destroy": (ctypes.c_int, [ctypes.c_void_p]),
@@ -78,6 +79,11 @@ class RcclComm:
     @property
     def callbacks(self):
         return self.lib.bcg_comm_rccl_callbacks(self.h).contents
+
+    @property
+    def communicators(self):
+        """2: the split exchange has a communicator of its own (default); 1: BCG_RCCL_SINGLE_COMM=1."""
+        return self.lib.bcg_comm_rccl_communicators(self.h)
 
     def last_error(self):
         return self.lib.bcg_rccl_last_error(self.h).decode()

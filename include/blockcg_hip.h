@@ -124,7 +124,8 @@ int bcg_force_generic(bcg_context* ctx, int enable);
  * the summation order of the fused Gram product.  Requires a 4-D lattice whose direction 3 is not divided over ranks,
  * R >= 3 and R | L3 (else BCG_ERR_UNSUPPORTED / BCG_ERR_INVALID); applies to the widths of the specialised stencil
  * (8, 16, 32 with L0 a multiple of the tile length), other widths keep the whole `tmp`.  Halo exchanges are issued per
- * chunk of R-2 slices and are not overlapped with arithmetic.  0 switches back. */
+ * chunk of R-2 slices; when the bcg_comm offers the split form and R >= 4 they overlap the stencil work on the neighbouring
+ * chunks (chunks of (R-2)/2 slices).  0 switches back. */
 int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
 /* Device memory one SBCGrQ solve of width m with n_shifts shifts occupies on this rank in the current mode: X_s, P_s,
  * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch -- and, outside capacity mode
@@ -134,6 +135,11 @@ int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
  * bit-identical; a solve that cannot allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation
  * switches the grouping off.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
+/* The same plan without a context or a device, for one rank of a process grid (a launcher sizing a run before it starts
+ * its ranks): ring_slices = 0 for a whole `tmp`; ring_overlapped = the per-chunk exchanges overlap (split callbacks
+ * present, ring >= 4); group_depth = iterations the shift updates are grouped over (1 = off, at most 4). */
+int bcg_sbcgrq_plan_bytes(int ndim, const int* global_dims, const int* grid, int m, int n_shifts, int consume_B, int ring_slices,
+                          int ring_overlapped, int group_depth, size_t* bytes_out);
 /* ... and one HALF-VOLUME solve (bcg_field_create_half below: all work fields hold V/2 sites, links stay full-volume) */
 int bcg_sbcgrq_device_bytes_half(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
 

@@ -17,6 +17,9 @@
  * exchange (halo_exchange_begin/end) runs on a second, higher-priority stream of this library: begin makes that
  * stream wait for the packed faces (an event on the context's stream) and posts the grouped sends/receives there;
  * end makes the context's stream wait for their completion.  The host never blocks in a callback.
+ * Each stream has a communicator of its own (the second one is ncclCommSplit of the first with a single colour, so one
+ * unique id still suffices): RCCL serialises launches of ONE communicator across streams with its own events, which
+ * would order an in-flight face exchange against the Gram all-reduce behind the caller's back.
  */
 #ifndef BLOCKCG_RCCL_H
 #define BLOCKCG_RCCL_H
@@ -47,6 +50,8 @@ int bcg_rccl_unique_id_file_done(const char* path, int rank, bcg_rccl_comm* comm
 int bcg_comm_rccl_create(bcg_context* ctx, const void* unique_id_bytes, int rank, int world, bcg_rccl_comm** out);
 /* The callback table that was installed (for callers that want to wrap or inspect it). */
 const bcg_comm* bcg_comm_rccl_callbacks(const bcg_rccl_comm* comm);
+/* How many RCCL communicators this transport drives: 2 (one per stream, the default) or 1 (BCG_RCCL_SINGLE_COMM=1). */
+int bcg_comm_rccl_communicators(const bcg_rccl_comm* comm);
 /* Host-side helpers a multi-process driver needs around its timed region: a barrier (all-reduce of one element +
  * stream synchronize) and the maximum of a host double over all ranks. */
 int bcg_rccl_barrier(bcg_rccl_comm* comm);

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -35,13 +36,20 @@ struct mockComm {
   std::string dir;
   std::map<int, uint64_t> sent, received;  // per peer: messages posted so far (matching order)
   uint64_t collectives = 0;
+  int splits = 0;                          // ncclCommSplit calls so far (collective: the same count on every rank)
 };
 typedef mockComm* ncclComm_t;
+typedef struct { int unused; } ncclConfig_t;
 
 namespace mock_rccl {
 struct Op { bool send; void* buf; size_t bytes; int peer; ncclComm_t comm; hipStream_t stream; };
-inline std::vector<Op>& group() { static std::vector<Op> g; return g; }
-inline int& depth() { static int d = 0; return d; }
+// group state is per THREAD, as in NCCL (tests/dist_threads_worker.py runs several ranks as threads of one process)
+inline std::vector<Op>& group() { static thread_local std::vector<Op> g; return g; }
+inline int& depth() { static thread_local int d = 0; return d; }
+// BCG_MOCK_SYNC=1: every call waits for its stream, moves the bytes on the calling thread and returns when they have
+// arrived -- for ranks that are threads of ONE process, where blocking host functions of several streams could end up
+// on one runtime callback thread and wait for each other.  The asynchronous form below is what the multi-process tests run.
+inline bool sync_mode() { static const bool s = std::getenv("BCG_MOCK_SYNC") && std::atoi(std::getenv("BCG_MOCK_SYNC")) != 0; return s; }
 inline bool write_file(const std::string& path, const void* data, size_t n) {
   const std::string tmp = path + ".tmp";
   FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -78,7 +86,8 @@ struct Job {
 };
 inline std::atomic<bool>& failed() { static std::atomic<bool> f{false}; return f; }
 struct Retired { hipEvent_t done; std::vector<void*> hosts; };
-inline std::vector<Retired>& retired() { static std::vector<Retired> r; return r; }
+inline std::vector<Retired>& retired() { static thread_local std::vector<Retired> r; return r; }
+inline hipError_t enqueue_host(hipStream_t s, Job* j);
 inline void collect(bool all) {  // free pinned buffers whose stream work has finished
   auto& r = retired();
   for (size_t i = 0; i < r.size();) {
@@ -114,6 +123,13 @@ inline void host_fn(void* arg) {  // no HIP calls in here
     if (!j->ar_remove.empty()) std::remove(j->ar_remove.c_str());
   }
   delete j;
+}
+inline hipError_t enqueue_host(hipStream_t s, Job* j) {
+  if (!sync_mode()) return hipLaunchHostFunc(s, host_fn, j);
+  const hipError_t e = hipStreamSynchronize(s);  // the device -> pinned copies of what is sent have landed
+  if (e != hipSuccess) { delete j; return e; }
+  host_fn(j);
+  return hipSuccess;
 }
 inline ncclResult_t finish(hipStream_t stream, std::vector<void*> hosts) {
   Retired r;
@@ -156,7 +172,7 @@ inline ncclResult_t run(const std::vector<Op>& ops) {
           recvs.emplace_back(h, &o);
         }
       }
-    if (hipLaunchHostFunc(s, host_fn, j) != hipSuccess) return ncclSystemError;
+    if (enqueue_host(s, j) != hipSuccess) return ncclSystemError;
     for (auto& r : recvs)
       if (hipMemcpyAsync(r.second->buf, r.first, r.second->bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclSystemError;
     if (finish(s, std::move(hosts)) != ncclSuccess) return ncclSystemError;
@@ -180,6 +196,17 @@ inline ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId i
   c->dir = std::string("/dev/shm/") + id.internal;
   mkdir(c->dir.c_str(), 0700);
   *comm = c;
+  return ncclSuccess;
+}
+// One colour only (what the transport asks for): a duplicate communicator with its own message and collective sequence.
+inline ncclResult_t ncclCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* out, ncclConfig_t*) {
+  if (!parent || !out || color != 0 || key != parent->rank) return ncclInvalidArgument;
+  mockComm* c = new mockComm();
+  c->rank = parent->rank;
+  c->world = parent->world;
+  c->dir = parent->dir + "/split" + std::to_string(parent->splits++);
+  mkdir(c->dir.c_str(), 0700);
+  *out = c;
   return ncclSuccess;
 }
 inline ncclResult_t ncclCommDestroy(ncclComm_t c) {
@@ -229,7 +256,7 @@ inline ncclResult_t ncclAllReduce(const void* in, void* out, size_t count, ncclD
   j->op = op;
   // the files of collective seq are removed when everyone has surely read them: at collective seq + 2
   if (seq >= 2) j->ar_remove = c->dir + "/ar_" + std::to_string(seq - 2) + "_" + std::to_string(c->rank);
-  if (hipLaunchHostFunc(s, mock_rccl::host_fn, j) != hipSuccess) return ncclSystemError;
+  if (mock_rccl::enqueue_host(s, j) != hipSuccess) return ncclSystemError;
   if (hipMemcpyAsync(out, h, count * 8, hipMemcpyHostToDevice, s) != hipSuccess) return ncclSystemError;
   return mock_rccl::finish(s, std::vector<void*>{h});
 }

@@ -244,3 +244,31 @@ def test_native_transport_multi_rank(dims, grid, m, ring, overlap, blocks):
     2 and 4 processes sharing the GPU, with RCCL's seven calls replaced by a host-staged stand-in that keeps their matching
     rules.  Every rank checks operator, Gram matrix and solve of its sub-lattice against the whole-lattice oracle."""
     _run_ranks(dims, grid, m, False, ring, blocks=blocks, patch="16,2,2", overlap=overlap, native=True)
+
+
+THREAD_CASES = [
+    # global dims,       grid,          m,  ring
+    ([32, 16, 8, 32], [2, 2, 2, 1], 16, 32),   # the headline's launch: ring 32 = L3, overlapped chunks of 15, 15 and 2 slices
+    ([32, 16, 8, 24], [2, 2, 2, 1], 16, 0),    # whole tmp: interior + boundary launches with three divided directions
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,ring", THREAD_CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_headline_process_grid_eight_ranks_as_threads(dims, grid, m, ring):
+    """BASELINE configs[3]'s process grid -- 8 ranks on (2,2,2,1): three divided directions, each two ranks wide, so every
+    rank exchanges two messages with the same peer in all three (posting-order matching) -- with `bench.py --gpus 8`'s
+    capacity ring (32 slices, overlapped chunks of C = 15: bundle-sweep windows with ring addressing and ghost faces in x0,
+    x1 and x2).  Eight GPU processes exceed what a one-GPU box admits (six), so the ranks are threads of one process over
+    the native transport's stand-in in its synchronous mode (tests/dist_threads_worker.py); each rank checks operator, Gram
+    matrix and a fixed-work solve against the whole-lattice oracle.  The bare 8-process launch of bench.py itself is
+    rehearsed without GPUs in tests/test_bench_launcher.py::test_bare_headline_command_plans_eight_ranks."""
+    env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)), BCG_TEST_M=str(m),
+               BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32", BCG_HOP_PATCH="16,2,2", BCG_MOCK_SYNC="1",
+               BCG_RCCL_LIB=_mock_transport())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_threads_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=1200)
+    _sweep_mock_files()
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert "DIST_THREADS_OK 8" in out.stdout
+    if ring:
+        assert "k_hop4b" in out.stdout  # the 15-slice windows ran the bundle sweep

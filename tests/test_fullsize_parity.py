@@ -64,9 +64,32 @@ OPERATOR_CASES = [
     ("64c4_m16_capacity8", [64, 64, 64, 64], 16, "capacity"),
     ("32c4_m8_default", [32, 32, 32, 32], 8, "default"),
     ("64c3x32_m32_default", [64, 64, 64, 32], 32, "default"),
-    ("64c3x128_m16_capacity8", [64, 64, 64, 128], 16, "capacity"),  # the per-GPU share of 128^4 on a (2,2,2,1) grid
-    ("64c3x128_m16_capacity16", [64, 64, 64, 128], 16, "capacity16"),  # ... with the ring bench.py --gpus 8 selects
+    ("64c3x128_m16_capacity8", [64, 64, 64, 128], 16, "capacity"),  # the per-GPU share of 128^4 on a (2,2,2,1) grid (row-form windows)
+    # ... with the ring `bench.py --gpus 8` selects, in both chunkings that ring runs: serial (one rank: C = 30, windows of
+    # 30, 30, 30, 30 and 8 slices) and the overlapped form's C = 15 (windows of 15 x 8 and 8), forced on this one rank
+    ("64c3x128_m16_capacity32", [64, 64, 64, 128], 16, "capacity32"),
+    ("64c3x128_m16_capacity32_chunks_of_15", [64, 64, 64, 128], 16, "capacity32c15"),
 ]
+
+
+def _capacity_of(mode):
+    """(ring slices, forced chunk length or 0) of a `capacity*` mode string"""
+    if not mode.startswith("capacity"):
+        return 0, 0
+    rest = mode[len("capacity"):]
+    ring, _, chunk = rest.partition("c")
+    return (int(ring) if ring else 8), (int(chunk) if chunk else 0)
+
+
+def _release(ctx, *objs):
+    """The 250-285 GB cases must give their memory back BEFORE the next case allocates: destroy the fields now (not when
+    the interpreter gets to the frame's locals), then the context, and collect."""
+    import gc
+    for o in objs:
+        for f in (o if isinstance(o, (list, tuple)) else [o]):
+            f.__del__()
+    ctx.close()
+    gc.collect()
 
 
 @pytest.mark.parametrize("case", OPERATOR_CASES, ids=[c[0] for c in OPERATOR_CASES])
@@ -78,9 +101,12 @@ def test_operator_production_geometry_vs_sampled_oracle(bc, orc, case, monkeypat
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("BCG_FORCE_TILE_CLASSES", "1" if mode == "classes" else "0")
     mass = 0.37
+    ring, chunk = _capacity_of(mode)
+    if chunk:
+        monkeypatch.setenv("BCG_RING_CHUNK", str(chunk))  # the overlapped form's chunk length on a rank without neighbours
     ctx = bc.Context(dims)
-    if mode.startswith("capacity"):
-        ctx.capacity_mode(16 if mode == "capacity16" else 8)
+    if ring:
+        ctx.capacity_mode(ring)
     D = bc.dirac_op(ctx, mass, seed=SEED_U)
     psi = bc.block_fermion_field(ctx, m).setRandom(seed=SEED_PSI)
     out = bc.block_fermion_field(ctx, m)
@@ -102,6 +128,7 @@ def test_operator_production_geometry_vs_sampled_oracle(bc, orc, case, monkeypat
         assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
     finally:
         orc.set_threads(1)
+        _release(ctx, psi, out, D)
 
 
 def tile_sites(a, base_dims, reps):
@@ -119,8 +146,8 @@ REPLICA_CASES = [
     ("64c4_m16_S2_tile_classes", [16, 8, 8, 16], [4, 8, 8, 4], 16, [0.0, 1e-2], "classes"),
     ("32c4_m8_S1", [16, 8, 8, 8], [2, 4, 4, 4], 8, [0.0], "default"),
     ("64c3x32_m32_S8", [16, 8, 8, 8], [4, 8, 8, 4], 32, [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0], "default"),
-    ("64c3x128_m16_S4_capacity8", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity"),
-    ("64c3x128_m16_S4_capacity16", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity16"),  # bench.py --gpus 8
+    ("64c3x128_m16_S4_capacity32", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity32"),  # bench.py --gpus 8's ring
+    ("64c3x128_m16_S4_capacity32_chunks_of_15", [16, 8, 8, 16], [4, 8, 8, 8], 16, [0.0, 1e-6, 1e-4, 1e-2], "capacity32c15"),
 ]
 
 
@@ -145,14 +172,22 @@ def test_replicated_solve_matches_oracle_on_base_lattice(bc, orc, case, monkeypa
         orc.set_threads(1)
     assert 3 < o["iterations"] < 2000
 
+    ring, chunk = _capacity_of(mode)
+    if chunk:
+        monkeypatch.setenv("BCG_RING_CHUNK", str(chunk))
     ctx = bc.Context(dims)
-    if mode.startswith("capacity"):
-        ctx.capacity_mode(16 if mode == "capacity16" else 8)
+    if ring:
+        ctx.capacity_mode(ring)
     D = bc.dirac_op(ctx, mass, U=tile_sites(Ub, base, reps))
     B = bc.block_fermion_field(ctx, m, tile_sites(Bb, base, reps))
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
-    info = bc.SBCGrQ(X, B, D, shifts, eps, eps, max_iterations=o["iterations"] + 50, trace_limit=ntrace,
-                     consume_B=mode.startswith("capacity"), return_info=True)
+    try:
+        info = bc.SBCGrQ(X, B, D, shifts, eps, eps, max_iterations=o["iterations"] + 50, trace_limit=ntrace,
+                         consume_B=mode.startswith("capacity"), return_info=True)
+        sites = chosen_sites(dims, n_special=300, n_random=200)
+        got = [X[s].download_sites(sites) for s in range(len(shifts))]
+    finally:
+        _release(ctx, X, B, D)
     assert abs(info["iterations"] - o["iterations"]) <= 1, (info["iterations"], o["iterations"])
     tr, otr = info["trace"], o["trace"]
     for key in ("alpha", "rho", "beta_s"):
@@ -160,12 +195,11 @@ def test_replicated_solve_matches_oracle_on_base_lattice(bc, orc, case, monkeypa
     for key in ("delta", "alpha_s"):  # these carry delta_0 = chol(B^dag B), which scales with sqrt(copies) (:115-116,167-168)
         assert rel_err(tr[key], np.sqrt(nrep) * otr[key]) < TOL_COEFF, key
     # X_full(x) = X_base(x mod base) at chosen sites of the full lattice
-    sites = chosen_sites(dims, n_special=300, n_random=200)
     x = [sites % dims[0], (sites // dims[0]) % dims[1], (sites // (dims[0] * dims[1])) % dims[2],
          sites // (dims[0] * dims[1] * dims[2])]
     bsite = (((x[3] % base[3]) * base[2] + x[2] % base[2]) * base[1] + x[1] % base[1]) * base[0] + x[0] % base[0]
     for s in range(len(shifts)):
-        assert rel_err(X[s].download_sites(sites), o["X"][s][bsite]) < 1e-7, s
+        assert rel_err(got[s], o["X"][s][bsite]) < 1e-7, s
 
 
 GRAM_CASES = [("64c4_m16", [64, 64, 64, 64], 16), ("32c4_m8", [32, 32, 32, 32], 8), ("64c3x32_m32", [64, 64, 64, 32], 32)]
@@ -192,6 +226,7 @@ def test_block_inner_products_at_full_size_vs_chunked_oracle(bc, orc, case):
     R = B.thinQR()   # in place: B becomes Q
     assert rel_err(R, orc.cholesky_upper(want_bb)) < 1e-11
     assert rel_err(B.hermitian_dot(B), np.eye(m)) < 1e-11
+    _release(ctx, A, B)
 
 
 @pytest.mark.parametrize("case", GRAM_CASES, ids=[c[0] for c in GRAM_CASES])
@@ -214,3 +249,4 @@ def test_row_kernels_at_full_size_vs_sampled_oracle(bc, orc, case):
     assert rel_err(new_y().rescale_add(M, B, 0.7).download_sites(sites), orc.rescale_add_matrix(y0, M, b0, 0.7)) < TOL_KERNEL
     assert rel_err(new_y().add(B, -0.3).download_sites(sites), orc.add_scalar(y0, b0, -0.3)) < TOL_KERNEL
     assert rel_err(new_y().multiply_upper_triangular_inverse_RHS(R).download_sites(sites), orc.tri_solve_rhs(y0, R)) < 1e-12
+    _release(ctx, B)
