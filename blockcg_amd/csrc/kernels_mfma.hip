@@ -83,6 +83,11 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #else
 #define BCG_HOP4B_DIR_BARRIER
 #endif
+// PIPE: the software-pipelined schedule of the bundle sweep (m = 16, 32; full-lattice form): every global access of a step is
+// an operation hipcc does not see, issued where it pays and retired by hand-counted s_waitcnt -- see "PIPE" in hop4b_body
+#ifndef BCG_HOP4B_PIPE
+#define BCG_HOP4B_PIPE 1
+#endif
 #ifndef BCG_HOP4B_STORE_SC1  // tuning builds: write-through output stores (the lines do not stay in the XCD's L2)
 #define BCG_HOP4B_STORE_SC1 0
 #endif
@@ -110,6 +115,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst));  // no "memory" clobber: it would force the callers' captured state into scratch;
 }                                            // the block barriers around every use order it against the compiler's LDS accesses
+// 4 bytes per active lane into LDS at `lds_dst` + 4 * lane: used to TOUCH memory (one lane per 128-byte line brings up to
+// 64 lines = 8 KB into the L2 with one instruction and no destination register; the bytes land in an unused LDS corner)
+__device__ __forceinline__ void glds4_touch(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst));
+}
+#ifndef BCG_HOP4B_TOUCH  // PIPE: touch the lines of slice x3 + 2 (own row, forward links, p) a step before their loads
+#define BCG_HOP4B_TOUCH 0
+#endif
+// The same with the source given as base + per-lane offset.  The scalar-base encoding of this instruction
+// (`global_load_lds_dwordx4 v_off, s[base:base+1]`) was tried to save the 64-bit vector address arithmetic in front of it:
+// the kernel then aborts at its first launch (two runs, with and without an immediate offset), so the address stays a VGPR pair.
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) { glds16_link(sbase + voff, lds_dst); }
 // One row element per lane (16 bytes at sbase + voff + IMM) by a load hipcc does not see: its result counts as available at
 // once, so the CALLER waits (s_waitcnt vmcnt) before the first use.  For values loaded one loop iteration ahead: hipcc's
 // own bookkeeping loses count across the loop's back edge and waits for every load of the NEW iteration at their use.
@@ -118,6 +138,17 @@ __device__ __forceinline__ dv2 ld_sv_async(const char* sbase, unsigned voff) {
   dv2 r;
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM));
   return r;
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate is part of the instruction): until at most
+// the n YOUNGEST vector-memory operations of the wave are outstanding.  n above the table waits for everything (stricter).
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+#define BCG_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    BCG_W(1) BCG_W(2) BCG_W(3) BCG_W(4) BCG_W(5) BCG_W(6) BCG_W(7) BCG_W(8) BCG_W(9) BCG_W(10) BCG_W(11) BCG_W(12)
+    BCG_W(13) BCG_W(14) BCG_W(15) BCG_W(16) BCG_W(17) BCG_W(18) BCG_W(19) BCG_W(20)
+#undef BCG_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
 }
 // link loads of the stencil (non-temporal loads were tried here: 13 % fewer L2 misses, no time gained)
 __device__ __forceinline__ dv2 ld_link(const dv2* p) { return *p; }
@@ -1858,6 +1889,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   // PREO (with ROWDMA): the two rows that leave the bundle are loaded ONE STEP AHEAD into registers, so that the first
   // three directions of a step wait for nothing and the step's only fresh data -- the +x3 row -- has them to arrive in
   constexpr bool PREO = ROWDMA && BCG_HOP4B_PREO != 0;
+  constexpr bool PIPE = BCG_HOP4B_PIPE != 0 && hop4b_share_images(M) && !CB && !RESID && !ROWDMA;
   constexpr int HB = 3 * M * 16;                  // bytes of one site = of one halo site
   constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site  // in-bundle backward links from the partner waves' images (2 images per wave)
   constexpr int RB = 3 * M * 16;           // bytes of one site of a field
@@ -1917,7 +1949,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   // variables themselves is turned into a select between their addresses, which keeps them in scratch
 #define BO_SEL(G, k) (BO_F(k) + ((G) ? ((k) == 0 ? bo_d0 : bo_d1) : 0u))
 #ifdef BCG_HOP4B_STAMPS  // diagnostic build (tools/hop_stamps.py 4b): where a step's cycles go, summed per wave
-  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long seg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_amdgcn_s_memtime();
 #define BCG_STAMPB(i)                                  \
   {                                                    \
@@ -2086,6 +2118,23 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           if (lane + 64 * k < SPW * 9) glds16_link(q2 + BO_SEL(k_b2, k), img + (NFW + SPW * 9 + 64 * k) * 16);
       }
     };
+    // ... and with the scalar-base form of the DMA (PIPE)
+    auto dma_links_at_s = [&](int x3, const char* fsrc, const char* lsrc, const char* q1, const char* q2) __attribute__((always_inline)) {
+      const unsigned img = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave)));
+      static_assert(!PIPE || (RFW <= 3 && RBK <= 2), "link DMA instructions per image");
+      if (lane < SPW * 36) glds16_s(fsrc, fo, img + 36 * 16);
+      if (RFW > 1 && lane + 64 < SPW * 36) glds16_s(fsrc, fo + 1024, img + (36 + 64) * 16);
+      if (RFW > 2 && lane + 128 < SPW * 36) glds16_s(fsrc, fo + 2048, img + (36 + 128) * 16);
+      if (lane < 9) glds16_s(lsrc, fo, img);
+      if (!e1) {
+        if (lane < SPW * 9) glds16_s(q1, BO_SEL(k_b1, 0), img + NFW * 16);
+        if (RBK > 1 && lane + 64 < SPW * 9) glds16_s(q1, BO_SEL(k_b1, 1), img + (NFW + 64) * 16);
+      }
+      if (!e2) {
+        if (lane < SPW * 9) glds16_s(q2, BO_SEL(k_b2, 0), img + (NFW + SPW * 9) * 16);
+        if (RBK > 1 && lane + 64 < SPW * 9) glds16_s(q2, BO_SEL(k_b2, 1), img + (NFW + SPW * 9 + 64) * 16);
+      }
+    };
     // CB: the links of the wave's SPW output sites of slice x3 -- every other site of a full-lattice row -- by LDS-DMA into
     // image(x3): forward links (one 36-entry record per site, the records 2 apart), then the backward links of all four
     // directions, each U_mu of the full-lattice site x - mu (periodic; the lattice is undivided).
@@ -2222,7 +2271,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     // step, as many as the step has FMAs.
     // In capacity mode the ring-addressed side (the output of the plain hop, the input rows of the shifted one) keeps the
     // closed form; links, p and the other side are carried.
-    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB && !ROWDMA && !PREO;
+    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB && !ROWDMA && !PREO;  // (PIPE below builds on it)
     constexpr bool INCR_IN = INCR && !RING_IN, INCR_OUT = INCR && !RING_OUT;
     const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
     const char* ik_f = nullptr; const char* ik_l = nullptr; const char* ik_1 = nullptr; const char* ik_2 = nullptr;
@@ -2290,6 +2339,335 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y), "+v"(o1[1].x), "+v"(o1[1].y), "+v"(o1[2].x), "+v"(o1[2].y));
       asm volatile("" : "+v"(o2[0].x), "+v"(o2[0].y), "+v"(o2[1].x), "+v"(o2[1].y), "+v"(o2[2].x), "+v"(o2[2].y));
     }
+    // ---- PIPE: the software-pipelined step -------------------------------------------------------------------------------
+    // What bounded the form below (profiles/r03_stencil_*): every wave of a block issued its ~21 vector-memory instructions
+    // -- 6 of them LDS-DMAs, the costliest to issue -- in one burst right behind the step's barrier (2.6 k of a step's 9.7 k
+    // cycles), waited for the first of them (1.9 k) and only then computed, with nothing in flight during the arithmetic.
+    // Here no global access is seen by hipcc (which would wait for ALL of them at the first use of ANY): they are issued in
+    // four small groups between the directions' arithmetic, in the order they are needed, and retired by hand-counted
+    // s_waitcnt (vector-memory operations complete in issue order; vmcnt(n) = all but the n youngest are done):
+    //   top      B  the +x3 row and its halo sites by LDS-DMA into the row slot (needed by direction 3 and by the next step);
+    //               the slot's old contents, the -x3 neighbour, are read into registers first
+    //   dir 0 |  E  p (shifted form; needed in the tail)    C  the links of slice x3 + 1 by LDS-DMA (needed after the next barrier)
+    //   dir 1 |  D  the two rows that leave the bundle, for step x3 + 1, into registers (needed in the next step)
+    //   dir 2
+    //   wait B (younger: E, C, D) | dir 3 | wait E (younger: C, D) | output | stores S | wait all but S | barrier
+    // so a step's loads have between one and three directions' arithmetic (and the partner wave's) to arrive in.
+    // Bit-identical to the other form: the same operands reach the same FMAs in the same order.
+    // tools/check_async_regs.py checks in the device code that nothing touches a destination register between issue and wait.
+    if constexpr (PIPE) {
+      dv2 q1[3], q2[3];  // rows that leave the bundle: this step's (complete)
+      {
+        const char* const a1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, win.x3_lo, slot);
+        const char* const a2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, win.x3_lo, slot);
+        if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double2 v1 = ld_sv(a1, voff, c * M * 16), v2 = ld_sv(a2, voff, c * M * 16);
+          q1[c] = dv2{v1.x, v1.y};
+          q2[c] = dv2{v2.x, v2.y};
+        }
+        // retired HERE (a load pending at the loop's entry would be waited for at its use in every iteration)
+        asm volatile("" : "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]));
+      }
+      constexpr int nB = 3 + 2 * NHD;                               // row DMAs
+      constexpr int nE = MODE == HOP_PLAIN ? 0 : 3;                 // p
+      const int nC = RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);     // link DMAs of this wave
+      constexpr int nD = 6, nS = 3;
+      (void)nB;
+      for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
+        const bool more = x3 + 1 < x3_end;
+        const int slot_n = RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0;
+        // pacing (thread 0; hipcc sees these few operations and waits for them itself -- at most the previous step's stores
+        // are outstanding here, and the counter traffic of the tail is issued behind the end-of-step wait, so none of the
+        // hand-counted waits below has one of them among the operations it counts)
+        const int step_n = vs0 + x3;
+        if (hw.sync != nullptr && tid == 0 && pace) {
+          const int need = step_n - hw.sync_window;
+          const unsigned known = seen2_idx == need ? seen2 : (seen1_idx == need ? seen1 : 0u);
+          if (need >= 0 && known < per) {
+            unsigned* ctr = hw.sync + cls * hw.sync_stride + need;
+            const long long t0 = wall_clock64();
+            while (read_counter(ctr, zero_rt) < per) {
+              if (wall_clock64() - t0 > hw.sync_limit) {
+                pace = false;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+        }
+        BCG_STAMPB(0)   // loop overhead, address bookkeeping, pacing wait of thread 0
+        __syncthreads();  // row slot x3 & 1 and link image x3 & 1 (filled during the previous step) are complete
+        BCG_STAMPB(1)   // barrier
+        const dv2* const Lf = image(x3, wave);
+        const dv2* const Lb = Lf + NFW;
+        const dv2* const ub1 = e1 ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
+        const dv2* const ub2 = e2 ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
+        const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;
+        dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;
+        dv2 f0[3], b0[3], b3[3], f3[3], lp1[3], lp2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b3[c] = Cn[co + c * M];  // -x3 neighbour: the slot's old contents
+        asm volatile("" : "+v"(b3[0]), "+v"(b3[1]), "+v"(b3[2]));  // in registers before the DMA below replaces them
+        // ---- B: slice x3 + 1 (own sites, halo sites) -> Cn
+        {
+          const char* own;
+          const char* lft;
+          const char* rgt;
+          if (INCR_IN && x3 + 1 < L3) {
+            own = ir_own; lft = ir_lft; rgt = ir_rgt;
+            ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
+          } else if (INCR_IN) {
+            own = iw_own; lft = iw_lft; rgt = iw_rgt;
+          } else {
+            int kind, xs, gx3;
+            slice_of(x3 + 1, slot_n, kind, xs, gx3);
+            row_ptrs3(kind, xs, gx3, own, lft, rgt);
+          }
+          const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(Cn));
+          glds16_s(own, fo, cn + HB);
+          glds16_s(own, fo + 1024, cn + HB + 1024);
+          glds16_s(own, fo + 2048, cn + HB + 2048);
+          static_assert(NHD <= 2, "halo site: at most two DMA instructions");
+          if (lane * 16 < HB) {
+            glds16_s(lft, fo, cn);
+            glds16_s(rgt, fo, cn + (SPW + 1) * HB);
+          }
+          if (NHD > 1 && lane * 16 + 1024 < HB) {
+            glds16_s(lft, fo + 1024, cn + 1024);
+            glds16_s(rgt, fo + 1024, cn + (SPW + 1) * HB + 1024);
+          }
+        }
+        BCG_STAMPB(2)   // -x3 read back, row DMAs issued
+        // neighbours inside the bundle, from the row slots of this slice
+        const dv2* const Cown = Cc + wave * CS;
+        const dv2* const Cp1 = Cc + (wave ^ 1) * CS;
+        const dv2* const Cp2 = Cc + (wave ^ 2) * CS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          f0[c] = Cown[co + 3 * M + c * M];
+          b0[c] = Cown[co - 3 * M + c * M];
+        }
+        const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
+        const char* const prow = INCR ? ip_p : reinterpret_cast<const char*>(p) + crow_site * RB;
+        char* const orow = INCR_OUT ? ip_o : reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
+        if (INCR) ip_p += id_row;
+        if (INCR_OUT) ip_o += id_row;
+        dv2 pv[3], n1[3], n2[3];
+        double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+        const int x0 = x0b + sw;
+        const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
+// The links are read from the images three entries of U_mu(x) and three of U_mu(x - mu) at a time -- the six a "unit" (mu, k) of
+// 24 FMAs needs -- one unit AHEAD of their use (two register slots, LU[(3 mu + k) & 1]), written out in that order in the
+// source: hipcc, left alone, issues each ds_read right in front of the FMAs that use it (it schedules for register
+// pressure) and the wave sits out the LDS latency ten times per direction.  (Two units ahead does not fit 256 registers.)
+// The order of the FMAs along each accumulation chain is that of the other form: bit-identical results.
+#define BCG_LD(S, K, UF, UB)                                                                                 \
+  {                                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+      LU[S][r] = (UF)[(K) * 3 + r];                                                                          \
+      LU[S][3 + r] = (UB)[r * 3 + (K)];                                                                      \
+    }                                                                                                        \
+  }
+#define BCG_FM(S, K, F, B)                                                                                   \
+  {                                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+      const dv2 u = LU[S][r];                                                                                \
+      t[r].x = fma(u.x, F[K].x, t[r].x); t[r].x = fma(-u.y, F[K].y, t[r].x);                                 \
+      t[r].y = fma(u.x, F[K].y, t[r].y); t[r].y = fma(u.y, F[K].x, t[r].y);                                  \
+      const dv2 v = LU[S][3 + r];                                                                            \
+      t[r].x = fma(-v.x, B[K].x, t[r].x); t[r].x = fma(-v.y, B[K].y, t[r].x);                                \
+      t[r].y = fma(-v.x, B[K].y, t[r].y); t[r].y = fma(v.y, B[K].x, t[r].y);                                 \
+    }                                                                                                        \
+  }
+// direction MU (S0: the slot of its unit 0 = MU & 1) with forward neighbour F, backward neighbour B; UFN / UBN: the next
+// direction's link pointers (unused if LAST); EXTRA: LDS reads the next direction needs, issued under this one's last unit
+#define BCG_PIPE_DIR(MU, S0, F, B, UFC, UBC, UFN, UBN, LAST, EXTRA)                                          \
+  {                                                                                                          \
+    const int par = (MU) == 0 ? 0 : ((MU) == 1 ? par1 : ((MU) == 2 ? par2 : par3));                         \
+    const double eta = (par & 1) ? -1.0 : 1.0;                                                               \
+    double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
+    if (LNKAHEAD) {                                                                                          \
+      BCG_LD(1 - (S0), 1, UFC, UBC)                                                                          \
+      BCG_FM(S0, 0, F, B)                                                                                    \
+      BCG_LD(S0, 2, UFC, UBC)                                                                                \
+      BCG_FM(1 - (S0), 1, F, B)                                                                              \
+      if (!(LAST)) BCG_LD(1 - (S0), 0, UFN, UBN)                                                             \
+      EXTRA                                                                                                  \
+      BCG_FM(S0, 2, F, B)                                                                                    \
+    } else { /* the form with the fused product has no registers to spare: each unit's links right in front of its FMAs */ \
+      BCG_LD(0, 0, UFC, UBC) BCG_FM(0, 0, F, B)                                                              \
+      BCG_LD(0, 1, UFC, UBC) BCG_FM(0, 1, F, B)                                                              \
+      EXTRA                                                                                                  \
+      BCG_LD(0, 2, UFC, UBC) BCG_FM(0, 2, F, B)                                                              \
+    }                                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+      acc[r].x = fma(eta, t[r].x, acc[r].x);                                                                 \
+      acc[r].y = fma(eta, t[r].y, acc[r].y);                                                                 \
+    }                                                                                                        \
+    BCG_PIPE_GROUPS(LAST)                                                                                    \
+  }
+// the order above, prescribed to the scheduler: 6 LDS reads, 24 FMAs, ... (BCG_HOP4B_LNKGRP=0: left to its heuristics)
+#ifndef BCG_HOP4B_LNKGRP
+#define BCG_HOP4B_LNKGRP 0
+#endif
+#if BCG_HOP4B_LNKGRP
+#define BCG_PIPE_GROUPS(LAST)                                   \
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);            \
+  __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);            \
+  __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);           \
+  if (!(LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); \
+  __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);
+#else
+#define BCG_PIPE_GROUPS(LAST)
+#endif
+// the partner waves' rows of this slice (x1 / x2 neighbours inside the bundle): read a direction ahead of their use
+#define BCG_LD_LP(LP, CP) { _Pragma("unroll") for (int c = 0; c < 3; ++c) LP[c] = (CP)[co + c * M]; }
+#define BCG_PIPE_PIN asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y))
+#define BCG_PIPE_APART(text) asm volatile("; " text : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y))
+        // (the shifted forms have p in flight besides: with the links a unit ahead they need 256 registers and spill 2-100 -- and a
+        //  spilled destination of a hand-waited load is read before it arrives; tools/check_async_regs.py, run by the Makefile)
+        constexpr bool LNKAHEAD = MODE == HOP_PLAIN;
+        dv2 LU[2][6];
+        const dv2* const uf0 = Lf + (sw + 1) * 36;          // U_mu(x): + 9 mu
+        const dv2* const ub0 = Lf + sw * 36;                // U_0(x - 0): the left neighbour's forward link
+        const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
+        if (LNKAHEAD) BCG_LD(0, 0, uf0, ub0)
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_PIPE_DIR(0, 0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG_LD_LP(lp1, Cp1))
+        BCG_PIPE_PIN;
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_STAMPB(3)   // direction 0
+        // ---- E: p;  C: links of slice x3 + 1 -> the other image
+        if (MODE != HOP_PLAIN) {
+          asm volatile("; ASYNC_ISSUE p");
+          pv[0] = ld_sv_async<0>(prow, voff);
+          pv[1] = ld_sv_async<M * 16>(prow, voff);
+          pv[2] = ld_sv_async<2 * M * 16>(prow, voff);
+          asm volatile("; ASYNC_ISSUED p");
+        }
+        if (more) {
+          if (INCR) {
+            dma_links_at_s(x3 + 1, ik_f, ik_l, ik_1, ik_2);
+            ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;
+          } else {
+            dma_links(x3 + 1, false);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_STAMPB(4)   // p loads and link DMAs issued
+        if (e1) { BCG_PIPE_DIR(1, 1, q1, lp1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2)) BCG_PIPE_APART("direction 1, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(1, 1, lp1, q1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2)) BCG_PIPE_APART("direction 1, backward row outside the bundle"); }
+        BCG_PIPE_PIN;
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_STAMPB(5)   // direction 1
+        // ---- D: the rows that leave the bundle, for the next step
+        if (more) {
+          const char* const a1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
+          const char* const a2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
+          if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
+          asm volatile("; ASYNC_ISSUE n");
+          n1[0] = ld_sv_async<0>(a1, voff);
+          n1[1] = ld_sv_async<M * 16>(a1, voff);
+          n1[2] = ld_sv_async<2 * M * 16>(a1, voff);
+          n2[0] = ld_sv_async<0>(a2, voff);
+          n2[1] = ld_sv_async<M * 16>(a2, voff);
+          n2[2] = ld_sv_async<2 * M * 16>(a2, voff);
+          asm volatile("; ASYNC_ISSUED n");
+        }
+        // ---- T (tuning build): touch what the step after next will load from HBM -- measured slower (profiles/r04_stencil_pipe.txt)
+        int nT = 0;
+        if (BCG_HOP4B_TOUCH != 0 && INCR_IN && x3 + 2 < x3_end && x3 + 2 < L3) {
+          const unsigned junk = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave))) + 9 * 16;
+          constexpr int LR = SPW * RB / 128, LK = SPW * 36 * 16 / 128;  // lines of a wave's row / of its forward links
+          static_assert(LR + LK <= 64 && (SPW * RB) % 128 == 0 && (SPW * 36 * 16) % 128 == 0, "touch: one lane per line");
+          const char* const t1 = lane < LR ? ir_own + lane * 128 : ik_f + (lane - LR) * 128;
+          if (lane < LR + LK) glds4_touch(t1, junk);
+          nT = 1;
+          if (MODE != HOP_PLAIN) {
+            if (lane < LR) glds4_touch(ip_p + id_row + lane * 128, junk);
+            nT = 2;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_STAMPB(6)   // next rows issued
+        if (e2) { BCG_PIPE_DIR(2, 0, q2, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(2, 0, lp2, q2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG_PIPE_APART("direction 2, backward row outside the bundle"); }
+        BCG_PIPE_PIN;
+        __builtin_amdgcn_sched_barrier(0);
+        BCG_STAMPB(7)   // direction 2
+        // ---- the +x3 row has landed in Cn once at most E, C and D (and the touches) are outstanding
+        wait_vmcnt(nE + (more ? nC + nD : 0) + nT);
+        BCG_STAMPB(8)   // wait for the +x3 row
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f3[c] = Cn[co + c * M];
+        BCG_PIPE_DIR(3, 1, f3, b3, uf0 + 27, ub3, uf0, ub0, true, )
+        BCG_PIPE_PIN;
+        __builtin_amdgcn_sched_barrier(0);
+#undef BCG_LD
+#undef BCG_FM
+#undef BCG_PIPE_DIR
+#undef BCG_PIPE_GROUPS
+#undef BCG_LD_LP
+#undef BCG_PIPE_PIN
+#undef BCG_PIPE_APART
+        BCG_STAMPB(9)   // direction 3
+        if (more) park_u3(x3 + 1);  // U_3(x - 3) of the next slice = U_3 of this one (ds_read / ds_write; the DMAs fill the rest)
+        double2 tv[3], pw[3];
+        if (MODE != HOP_PLAIN) {
+          wait_vmcnt((more ? nC + nD : 0) + nT);  // p
+          // The values are handed to hipcc as NEW registers written behind the wait (plain inputs, early-clobber outputs): with
+          // the loaded registers as in-out operands of an empty asm the allocator may pick other registers for the operand
+          // and copy -- i.e. read -- the loaded ones in FRONT of the wait (it did, for the rows below).
+          dv2 r0, r1, r2;
+          asm volatile("; ASYNC_RETIRE p\n\tv_mov_b64 %0, %6\n\tv_mov_b64 %1, %7\n\tv_mov_b64 %2, %8\n\tv_mov_b64 %3, %9\n\tv_mov_b64 %4, %10\n\tv_mov_b64 %5, %11"
+                       : "=&v"(r0.x), "=&v"(r0.y), "=&v"(r1.x), "=&v"(r1.y), "=&v"(r2.x), "=&v"(r2.y)
+                       : "v"(pv[0].x), "v"(pv[0].y), "v"(pv[1].x), "v"(pv[1].y), "v"(pv[2].x), "v"(pv[2].y));
+          pw[0] = make_double2(r0.x, r0.y);
+          pw[1] = make_double2(r1.x, r1.y);
+          pw[2] = make_double2(r2.x, r2.y);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
+          else tv[r] = make_double2(fma(c0, pw[r].x, -0.5 * acc[r].x), fma(c0, pw[r].y, -0.5 * acc[r].y));
+          st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
+        }
+        if (GRAM) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) gram_step<16>(G, &pw[r], &tv[r]);
+        }
+        BCG_STAMPB(10)  // U_3 carried, wait for p, output, stores
+        // everything but the stores: the links and the next rows have landed before this wave reaches the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        if (BCG_HOP4B_TOUCH != 0) wait_vmcnt(nS + nT);  // (the touches stay in flight; everything older has landed)
+        if (more) {
+          asm volatile("s_waitcnt vmcnt(%24) ; ASYNC_RETIRE n\n\t"
+                       "v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\tv_mov_b64 %2, %14\n\tv_mov_b64 %3, %15\n\tv_mov_b64 %4, %16\n\tv_mov_b64 %5, %17\n\t"
+                       "v_mov_b64 %6, %18\n\tv_mov_b64 %7, %19\n\tv_mov_b64 %8, %20\n\tv_mov_b64 %9, %21\n\tv_mov_b64 %10, %22\n\tv_mov_b64 %11, %23"
+                       : "=&v"(q1[0].x), "=&v"(q1[0].y), "=&v"(q1[1].x), "=&v"(q1[1].y), "=&v"(q1[2].x), "=&v"(q1[2].y),
+                         "=&v"(q2[0].x), "=&v"(q2[0].y), "=&v"(q2[1].x), "=&v"(q2[1].y), "=&v"(q2[2].x), "=&v"(q2[2].y)
+                       : "v"(n1[0].x), "v"(n1[0].y), "v"(n1[1].x), "v"(n1[1].y), "v"(n1[2].x), "v"(n1[2].y),
+                         "v"(n2[0].x), "v"(n2[0].y), "v"(n2[1].x), "v"(n2[1].y), "v"(n2[2].x), "v"(n2[2].y),
+                         "n"(BCG_HOP4B_TOUCH != 0 ? nS + 2 : nS)
+                       : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(nS) : "memory");  // (no touch is issued in a column's last two steps)
+        }
+        if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
+          __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen2 = seen1;
+        seen2_idx = seen1_idx;
+        if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window) {
+          seen1_idx = step_n + 2 - hw.sync_window;
+          seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
+        }
+        if (RING) slot = slot_n;
+        BCG_STAMPB(11)  // end-of-step wait (links, next rows), pacing counters
+      }
+    } else
     for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
       const int step_n = vs0 + x3;
       if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
@@ -2660,8 +3038,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   }
 #ifdef BCG_HOP4B_STAMPS
   if (!GRAM && lane == 0) {
-    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 8;
-    for (int i = 0; i < 8; ++i) o[i] = static_cast<double>(seg[i]);
+    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 16;
+    for (int i = 0; i < 16; ++i) o[i] = static_cast<double>(seg[i]);
   }
 #endif
 #undef BCG_STAMPB

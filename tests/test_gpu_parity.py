@@ -491,7 +491,10 @@ def test_capacity_mode_matches_default_and_oracle(bc, orc, m, dims, ring, walk, 
     field = V * 3 * m * 16
     # what the mode is for: the ring instead of the intermediate field, and none of the two further residual buffers of
     # the shift updates grouped over four iterations (pair_shifts_depth: m = 8, 16; capacity mode groups two, for free)
-    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (2 * field if m in (8, 16) else 0)
+    # (at m = 16 the ring sweep keeps the fused product's block partials of all its chunks side by side: 1024 blocks x chunks)
+    chunks = -(-dims[3] // (ring - 2))
+    more_partials = max(0, 1024 * chunks * m * m * 16 - 2048 * 32 * 32 * 16) if m == 16 else 0
+    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (2 * field if m in (8, 16) else 0) - more_partials
 
 
 def test_capacity_mode_arguments(bc):

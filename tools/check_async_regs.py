@@ -1,39 +1,102 @@
 #!/usr/bin/env python3
-"""Build-time check for k_hop4b's hand-waited loads (ld_sv_async, BCG_HOP4B_PREO): between their issue and the hand-written
-`s_waitcnt vmcnt(0)` that retires them, no instruction may read or copy their destination registers (hipcc believes the
-values are there from the start).  usage: tools/check_async_regs.py <device asm from hipcc -S --cuda-device-only>"""
+"""Build-time check for k_hop4b's hand-waited global loads (ld_sv_async in the PIPE schedule).
+
+hipcc does not see these loads (inline asm): it believes their destination registers hold the values from the moment of
+issue.  Correctness therefore needs that between a group's ISSUE and the hand-written wait that RETIRES it no instruction
+on the path reads, copies or overwrites those registers.  The kernel brackets every group with asm comments
+    ; ASYNC_ISSUE <tag>  ...loads...  ; ASYNC_ISSUED <tag>      and marks the point behind the retiring wait     ; ASYNC_RETIRE <tag>
+and this script walks the device assembly of every k_hop4b instantiation from ISSUED along the control flow (unconditional
+branches are followed, conditional ones fork) to the RETIRE marker or to a hand-written end-of-step wait (vmcnt(3) or
+less): no instruction on any such path may name a destination register of the group, and every path must end in one.
+
+usage: tools/check_async_regs.py <device asm from `hipcc -S --cuda-device-only`>   exit status 1 on a violation
+"""
 import re
 import sys
 
-txt = open(sys.argv[1]).read()
-ok = True
-for m in re.finditer(r'^(_ZN3bcg\S*k_hop4b[^:\s]*):[^\n]*\n(.*?)s_endpgm', txt, re.S | re.M):
-    lines = m.group(2).split('\n')
-    idx = [i for i, l in enumerate(lines) if 'global_load_dwordx4' in l and ' lds' not in l and 'ASMSTART' in lines[i - 1]]
-    if not idx:
-        continue
-    # the loop body: the last contiguous group of six
-    idx = idx[-6:]
-    regs = set()
-    for i in idx:
-        r = re.search(r'v\[(\d+):(\d+)\]', lines[i])
-        regs |= set(range(int(r.group(1)), int(r.group(2)) + 1))
-    j = idx[-1] + 1
-    while j < len(lines) and not ('s_waitcnt vmcnt(0)' in lines[j] and 'ASMSTART' in lines[j - 1]):
-        j += 1
-    bad = []
-    for k in range(idx[0] + 1, j):
-        if k in idx:
-            continue
-        l = lines[k].split(';')[0]
-        used = set()
-        for a, b in re.findall(r'v\[(\d+):(\d+)\]', l):
-            used |= set(range(int(a), int(b) + 1))
-        used |= {int(r) for r in re.findall(r'\bv(\d+)\b', l)}
-        if used & regs:
-            bad.append((k, lines[k].strip()))
-    print(m.group(1)[:60], 'async regs', min(regs), '-', max(regs), 'instructions to the wait:', j - idx[-1], 'touched:', len(bad))
-    for b in bad[:8]:
-        print('   ', b)
-    ok = ok and not bad
-sys.exit(0 if ok else 1)
+
+def regs_of(text):
+    used = set()
+    for a, b in re.findall(r'\bv\[(\d+):(\d+)\]', text):
+        used |= set(range(int(a), int(b) + 1))
+    used |= {int(r) for r in re.findall(r'\bv(\d+)\b', text)}
+    return used
+
+
+def main(path):
+    txt = open(path).read()
+    ok = True
+    seen = 0
+    for m in re.finditer(r'^(_ZN3bcg\S*k_hop4b[^:\s]*):[^\n]*\n(.*?)s_endpgm', txt, re.S | re.M):
+        lines = m.group(2).split('\n')
+        label = {l.split(':')[0]: i for i, l in enumerate(lines) if re.match(r'^\.LBB\w+:', l)}
+        starts = [(i, l.split('ASYNC_ISSUE ')[1].split()[0]) for i, l in enumerate(lines) if 'ASYNC_ISSUE ' in l]
+        for i, tag in starts:
+            seen += 1
+            j = i + 1
+            regs = set()
+            while j < len(lines) and f'ASYNC_ISSUED {tag}' not in lines[j]:
+                d = re.search(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', lines[j])
+                if d:
+                    regs |= set(range(int(d.group(1)), int(d.group(2)) + 1))
+                j += 1
+            todo, done, bad, reached, lost = [j + 1], set(), [], 0, 0
+            why = []
+            walked = 0
+            while todo:
+                k = todo.pop()
+                while True:
+                    if k in done:
+                        break
+                    done.add(k)
+                    if k >= len(lines):
+                        lost += 1
+                        why.append('ran off the end')
+                        break
+                    if f'ASYNC_RETIRE {tag}' in lines[k]:
+                        reached += 1
+                        break
+                    # the end-of-step wait on the path that issued nothing (`more` false: the walker cannot know that the
+                    # issue and this path exclude each other) retires everything but the stores just the same
+                    w = re.search(r's_waitcnt\s+vmcnt\((\d+)\)', lines[k])
+                    if w and int(w.group(1)) <= 3 and k > 0 and 'ASMSTART' in lines[k - 1]:
+                        reached += 1
+                        break
+                    if f'ASYNC_ISSUE {tag}' in lines[k]:  # came round the loop without a retire
+                        lost += 1
+                        why.append(f'reached the next issue at line {k}')
+                        break
+                    l = lines[k].split(';')[0].strip()
+                    walked += 1
+                    if l and not l.startswith('.') and not l.endswith(':') and regs_of(l) & regs:
+                        bad.append((k, lines[k].strip()))
+                    b = re.match(r's_branch\s+(\S+)', l)
+                    if b:
+                        k = label[b.group(1)]
+                        continue
+                    c = re.match(r's_cbranch_\w+\s+(\S+)', l)
+                    if c:
+                        todo.append(label[c.group(1)])
+                    if re.match(r's_setpc|s_swappc', l):  # a jump table: cannot follow
+                        lost += 1
+                        why.append(f'jump table at line {k}')
+                        break
+                    k += 1
+            # statically infeasible paths (the issue sits under `more`, some waits under `!more`) may wander past the loop: they are
+            # walked and checked like the others; what must hold is that NO walked instruction touches the registers
+            good = reached > 0 and not bad and regs
+            print(m.group(1)[28:62], f'group {tag}: v{min(regs)}..v{max(regs)}, {walked} instructions walked, paths to the retire:',
+                  reached, 'lost:', lost, 'touched in between:', len(bad))
+            for b_ in bad[:6]:
+                print('     ', b_)
+            for w_ in why:
+                print('      (path left the step without a retire marker:', w_ + ')')
+            ok = ok and bool(good)
+    if seen == 0:
+        print('no hand-waited load groups found (not a PIPE build?)')
+        return 1
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1]))
