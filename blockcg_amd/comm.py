@@ -168,9 +168,10 @@ class TorchDistComm:
             msgs = [(peer_s[k], peer_r[k], off_s[k], off_r[k], nbytes[k]) for k in range(n)]
             with torch.cuda.stream(self.stream):
                 if self.direct:
-                    self._pending = post_messages(send, recv, msgs, self.group)
+                    self._pending.append(post_messages(send, recv, msgs, self.group))
                 else:  # host-staged transport has nothing to overlap: do it all now
                     exchange_messages(send, recv, msgs, self.group, False, sync=self.stream.synchronize)
+                    self._pending.append([])
             return 0
         except Exception as e:
             self.error = e
@@ -179,9 +180,8 @@ class TorchDistComm:
     def _halo_end(self, user):
         try:
             with torch.cuda.stream(self.stream):
-                for w in self._pending:
+                for w in self._pending.pop(0):  # exchanges end in the order they began (up to two outstanding)
                     w.wait()  # the context's stream waits for the exchange; the host does not block
-            self._pending = []
             return 0
         except Exception as e:
             self.error = e

@@ -373,19 +373,28 @@ int halo_plan(int ndim, const int* gdims, const int* grid, const int* coords, si
 // Post the face messages for `site_bytes` bytes per site (fields: 3*m*16; gauge: 9*16).  split = true uses the
 // begin half of the optional split form (the caller then issues exchange_end after the interior tiles).
 // x3_n > 0 (direction 3 undivided): only the slices [x3_lo, x3_lo + x3_n), a contiguous sub-range of every face.
-int exchange_faces(bcg_context* c, size_t site_bytes, bool split = false, int x3_lo = 0, int x3_n = 0) {
+// x3b_n > 0: a second range of slices in the same exchange (the messages of the first range, then those of the second)
+int exchange_faces(bcg_context* c, size_t site_bytes, bool split = false, int x3_lo = 0, int x3_n = 0, int x3b_lo = 0, int x3b_n = 0) {
   if (!c->have_comm || !c->comm.halo_exchange) BCG_FAIL(c, BCG_ERR_COMM, "lattice is split over ranks but no bcg_comm was set");
-  int peer_s[8], peer_r[8];
-  size_t off_s[8], off_r[8], nb[8];
-  const int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
+  int peer_s[16], peer_r[16];
+  size_t off_s[16], off_r[16], nb[16];
+  int n = halo_plan(c->ndim, c->gdims, c->grid, c->coords, site_bytes, peer_s, peer_r, off_s, off_r, nb, nullptr);
   if (n < 0) BCG_FAIL(c, BCG_ERR_INVALID, "halo plan");
   if (x3_n > 0) {
     for (int k = 0; k < n; ++k) {
       const size_t slice = nb[k] / c->lat.L[3];
+      if (x3b_n > 0) {
+        peer_s[n + k] = peer_s[k];
+        peer_r[n + k] = peer_r[k];
+        off_s[n + k] = off_s[k] + slice * x3b_lo;
+        off_r[n + k] = off_r[k] + slice * x3b_lo;
+        nb[n + k] = slice * x3b_n;
+      }
       off_s[k] += slice * x3_lo;
       off_r[k] += slice * x3_lo;
       nb[k] = slice * x3_n;
     }
+    if (x3b_n > 0) n *= 2;
   }
   auto fn = split ? c->comm.halo_exchange_begin : c->comm.halo_exchange;
   if (fn(c->comm.user, n, peer_s, peer_r, off_s, off_r, nb) != 0) BCG_FAIL(c, BCG_ERR_COMM, "halo_exchange callback failed");
@@ -414,17 +423,20 @@ int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
 
 // Faces of the x3 slices [x3_lo, x3_lo + x3_n) only; `d` is a whole field (ring = 0) or a ring of slices (capacity mode).
 // The other slices' ranges of the ghost buffer keep what they held.
-int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring, bool split = false) {
+// x3b_n > 0: and those of a second range of slices, in the same exchange
+int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring, bool split = false, int x3b_lo = 0,
+                int x3b_n = 0) {
   if (!c->distributed) return BCG_OK;
   const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
   BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
   {
     ProfScope ps(c, "pack_faces");
     bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3_lo, x3_n, ring);
+    if (x3b_n > 0) bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3b_lo, x3b_n, ring);
   }
   BCG_TRY(check_launch(c, "pack_faces"));
   ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
-  return exchange_faces(c, site_bytes, split, x3_lo, x3_n);
+  return exchange_faces(c, site_bytes, split, x3_lo, x3_n, x3b_lo, x3b_n);
 }
 
 // Capacity mode with overlapped exchanges: the received faces of slice x3 = 0 of every split direction, saved aside
@@ -749,7 +761,25 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   const bool gram = gram_blocks && m == 16;
   const bcg::HopTuning& tune = c->hop_tune;
   const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
-  BCG_TRY(halo_field(c, P));
+  // The source's faces.  Serial form: one blocking exchange of the whole field.  Overlapped form: nothing blocks -- the
+  // faces of the slices the first launches read (the wrap slice L3 - 1 and slices 0 .. C, tmp up to one slice past the
+  // first chunk) go first, the rest behind them as a second outstanding exchange that travels while those launches run and is ended
+  // in front of the first launch that reads it (the transport ends exchanges in the order they began).
+  bool p_rest_pending = false;
+  if (overlap && c->distributed) {
+    const int n1 = (C + 1 < L3 - 1) ? C + 1 : L3 - 1;  // slices [0, n1) and slice L3 - 1
+    BCG_TRY(halo_window(c, m, P->d, 0, n1, 0, /*split=*/true, L3 - 1, 1));
+    if (n1 < L3 - 1) {
+      BCG_TRY(halo_window(c, m, P->d, n1, L3 - 1 - n1, 0, /*split=*/true));
+      p_rest_pending = true;
+    }
+    {
+      ProfScope ps(c, "halo_exchange_end");
+      BCG_TRY(exchange_end(c));
+    }
+  } else {
+    BCG_TRY(halo_field(c, P));
+  }
   if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/true));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
     note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
@@ -801,6 +831,11 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     BCG_TRY(halo_window(c, m, ring, 0, (C < L3 ? C : L3), R, /*split=*/true));
     for (int lo = 0; lo < L3; lo += C) {
       const int hi = lo + C < L3 ? lo + C : L3;
+      if (p_rest_pending) {  // the rest of the source's faces: posted before chunk 0's tmp faces, so ended before them
+        ProfScope ps(c, "halo_exchange_end");
+        BCG_TRY(exchange_end(c));
+        p_rest_pending = false;
+      }
       if (hi < L3) BCG_TRY(stage_first(hi));  // chunk k + 1's slices of tmp, while chunk k's faces are on the links
       {
         ProfScope ps(c, "halo_exchange_end");

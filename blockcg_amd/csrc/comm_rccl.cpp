@@ -24,7 +24,9 @@ struct bcg_rccl_comm {
   int rank = 0, world = 1, device = 0;
   hipStream_t ctx_stream = nullptr;   // the context's stream (not owned)
   hipStream_t xfer_stream = nullptr;  // split exchange: higher priority than the compute stream
-  hipEvent_t packed = nullptr, arrived = nullptr;
+  hipEvent_t packed = nullptr;
+  hipEvent_t arrived[2] = {nullptr, nullptr};  // up to two exchanges outstanding, ended in the order they began
+  unsigned begun = 0, ended = 0;
   double* scratch = nullptr;          // one device double for barrier / max
   bcg_comm table{};
   std::string err;
@@ -92,13 +94,17 @@ int cb_halo_begin(void* user, int n, const int* ps, const int* pr, const size_t*
   bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
   HIP_OK(c, hipEventRecord(c->packed, c->ctx_stream));            // the faces are packed once this fires
   HIP_OK(c, hipStreamWaitEvent(c->xfer_stream, c->packed, 0));
+  if (c->begun - c->ended >= 2) { fail(c, "halo_exchange_begin: two exchanges are already outstanding"); return 1; }
   if (post_group(c, c->halo_comm, c->xfer_stream, n, ps, pr, os, orr, nb) != 0) return 1;
-  HIP_OK(c, hipEventRecord(c->arrived, c->xfer_stream));
+  HIP_OK(c, hipEventRecord(c->arrived[c->begun & 1], c->xfer_stream));
+  c->begun += 1;
   return 0;
 }
 int cb_halo_end(void* user) {
   bcg_rccl_comm* c = static_cast<bcg_rccl_comm*>(user);
-  HIP_OK(c, hipStreamWaitEvent(c->ctx_stream, c->arrived, 0));    // boundary tiles read the ghosts after this
+  if (c->ended == c->begun) { fail(c, "halo_exchange_end without an exchange outstanding"); return 1; }
+  HIP_OK(c, hipStreamWaitEvent(c->ctx_stream, c->arrived[c->ended & 1], 0));  // the oldest outstanding exchange: its ghosts may be read after this
+  c->ended += 1;
   return 0;
 }
 int cb_allreduce(void* user, void* buf, size_t count) {
@@ -217,7 +223,8 @@ int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int w
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
   if (hipStreamCreateWithPriority(&c->xfer_stream, hipStreamNonBlocking, hi) != hipSuccess ||
       hipEventCreateWithFlags(&c->packed, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->arrived[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->arrived[1], hipEventDisableTiming) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->scratch), sizeof(double)) != hipSuccess)
     return bail("stream/event/scratch creation failed", BCG_ERR_HIP);
   c->table.user = c;
@@ -259,7 +266,8 @@ int bcg_comm_rccl_destroy(bcg_rccl_comm* c) {
     (void)hipStreamDestroy(c->xfer_stream);
   }
   if (c->packed) (void)hipEventDestroy(c->packed);
-  if (c->arrived) (void)hipEventDestroy(c->arrived);
+  for (hipEvent_t e : c->arrived)
+    if (e) (void)hipEventDestroy(e);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->halo_comm_own && c->halo_comm) (void)ncclCommDestroy(c->halo_comm);
   if (c->comm) (void)ncclCommDestroy(c->comm);

@@ -72,7 +72,10 @@ typedef struct bcg_comm {
   /* Optional split form of halo_exchange (both NULL or both set).  begin posts the same messages, ordered after the
    * work already enqueued on the context's stream, and returns without making the stream wait; end makes the stream
    * wait for their completion.  Between the two the library enqueues the stencil over the interior tiles, which read
-   * no ghost site, so the exchange overlaps that arithmetic; the boundary tiles follow end. */
+   * no ghost site, so the exchange overlaps that arithmetic; the boundary tiles follow end.
+   * Up to TWO exchanges may be outstanding (capacity mode posts the faces of the source in two windows and the first
+   * chunk's `tmp` faces behind them); halo_exchange_end ends the OLDEST one.  Their send and receive ranges are disjoint;
+   * a transport may run them one after the other.  n_msgs is at most 16 (a window may consist of two x3 ranges). */
   int (*halo_exchange_begin)(void* user, int n_msgs, const int* peer_send, const int* peer_recv, const size_t* send_offset,
                              const size_t* recv_offset, const size_t* nbytes);
   int (*halo_exchange_end)(void* user);

@@ -59,6 +59,7 @@ def main():
     if os.environ.get("BCG_TEST_EXPECT_RING_OVERLAP") == "1":  # capacity mode took the overlapped form: split exchanges per chunk
         assert prof.get("halo_exchange_begin", {}).get("count", 0) >= 2 and "hop_ring" in prof, prof
         assert prof["halo_exchange_end"]["count"] == prof["halo_exchange_begin"]["count"], prof
+        assert "halo_exchange" not in prof, sorted(prof)  # the source's faces travel in the split form too: nothing blocks
     orc = oracle.Oracle()
     V = int(np.prod(gdims))
     U = orc.fill_gauge(gdims, 3)

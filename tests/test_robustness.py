@@ -132,9 +132,15 @@ def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypat
         if limit:
             # still to come inside begin / the first iteration: P_s (4), T, Q (B is kept), tmp = 7 fields + scratch (< 100 MB)
             spare = 7 * field + field * 3 // 2 + (100 << 20)
-            free = _free_bytes()
-            assert free > spare
-            ballast = torch.empty(free - spare, dtype=torch.uint8, device="cuda")
+            torch.cuda.empty_cache()  # (torch would serve the ballast from blocks it has cached: free memory would not move)
+            ballast = []
+            for _ in range(4):  # until the runtime itself reports `spare` (+ < 64 MB) free
+                free = _free_bytes()
+                assert free > spare
+                if free - spare < (64 << 20):
+                    break
+                ballast.append(torch.empty(free - spare, dtype=torch.uint8, device="cuda"))
+            assert _free_bytes() - spare < (64 << 20)
         st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
         st.iterate(iters)
         st.end()
@@ -148,7 +154,7 @@ def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypat
 
     a, pa = run(limit=True)
     b, pb = run(limit=False)
-    assert "phaseC_multi3" in pa and "phaseC_multi4" not in pa, sorted(pa)   # depth 3 under the limit
+    assert "phaseC_multi3" in pa and "phaseC_multi4" not in pa, sorted(k for k in pa if k.startswith("phaseC"))  # depth 3 under the limit
     assert "phaseC_multi4" in pb                                               # depth 4 with room
     for s in range(len(shifts)):
         assert np.array_equal(a[s], b[s])  # the grouping depth never changes the iterates
