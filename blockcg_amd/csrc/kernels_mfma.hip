@@ -62,44 +62,18 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
                                // 1 where measured faster -- plain hop 10.05-10.23 vs 10.31-10.49 ms, with the fused Gram
                                // product 12.05-12.37 vs 11.90-12.16 (profiles/r03_stencil_incremental_addresses.txt)
 #endif
-// -DBCG_HOP4B_INCR_CHECK: test build -- every carried address is compared with its closed form at every step and a mismatch
-// poisons the output (the closed form is what is used).  -DBCG_HOP4B_EXPERIMENT=<bits>: timing builds that leave parts of a
-// step out and compute WRONG results on purpose (profiles/r03_stencil_ablation.txt); never linked into the product library.
-#ifndef BCG_HOP4B_ROWDMA   // tuning builds (tools/build_variant.sh): the +x3 row by LDS-DMA straight into its row slot
-#define BCG_HOP4B_ROWDMA 0
-#endif
-#ifndef BCG_HOP4B_PREO     // tuning builds: with ROWDMA, the rows that leave the bundle one step ahead
-#define BCG_HOP4B_PREO 0
-#endif
-// tuning builds: what may be scheduled across the start of a direction's arithmetic in k_hop4b (0: nothing, the default;
-// 1: LDS reads -- the next direction's link reads may start under this direction's FMAs; 2: no scheduling barrier)
-#ifndef BCG_HOP4B_SCHED
-#define BCG_HOP4B_SCHED 0
-#endif
-#if BCG_HOP4B_SCHED == 0
-#define BCG_HOP4B_DIR_BARRIER __builtin_amdgcn_sched_barrier(0)
-#elif BCG_HOP4B_SCHED == 1
-#define BCG_HOP4B_DIR_BARRIER __builtin_amdgcn_sched_barrier(0x100)
-#else
-#define BCG_HOP4B_DIR_BARRIER
-#endif
 // PIPE: the software-pipelined schedule of the bundle sweep (m = 16, 32; full-lattice form): every global access of a step is
-// an operation hipcc does not see, issued where it pays and retired by hand-counted s_waitcnt -- see "PIPE" in hop4b_body
+// an operation hipcc does not see, issued where it pays and retired by hand-counted s_waitcnt -- see "PIPE" in hop4b_body.
+// -DBCG_HOP4B_PIPE=0 is the A/B build: the step of rounds 1-3 (still what m = 8, the checkerboard and the residual form run).
+// The tuning builds of round 3 (the +x3 row by LDS-DMA, rows one step ahead, scheduling-barrier masks, write-through stores,
+// non-temporal link DMAs, the ablations of profiles/r03_stencil_ablation.txt, the carried-address check) have been removed:
+// their results are recorded in profiles/r03_stencil_*.txt and DESIGN_HISTORY.md, and PIPE supersedes what they explored.
 #ifndef BCG_HOP4B_PIPE
 #define BCG_HOP4B_PIPE 1
 #endif
-#ifndef BCG_HOP4B_STORE_SC1  // tuning builds: write-through output stores (the lines do not stay in the XCD's L2)
-#define BCG_HOP4B_STORE_SC1 0
-#endif
-#ifdef BCG_HOP4B_LINK_NT     // tuning builds: non-temporal link DMAs
-#define BCG_GLDS_LINK_AUX " nt"
-#else
-#define BCG_GLDS_LINK_AUX ""
-#endif
 __device__ __forceinline__ void glds16_link(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" BCG_GLDS_LINK_AUX
-               "\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst));
 }
@@ -115,17 +89,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst));  // no "memory" clobber: it would force the callers' captured state into scratch;
 }                                            // the block barriers around every use order it against the compiler's LDS accesses
-// 4 bytes per active lane into LDS at `lds_dst` + 4 * lane: used to TOUCH memory (one lane per 128-byte line brings up to
-// 64 lines = 8 KB into the L2 with one instruction and no destination register; the bytes land in an unused LDS corner)
-__device__ __forceinline__ void glds4_touch(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst));
-}
-#ifndef BCG_HOP4B_TOUCH  // PIPE: touch the lines of slice x3 + 2 (own row, forward links, p) a step before their loads
-#define BCG_HOP4B_TOUCH 0
-#endif
 // The same with the source given as base + per-lane offset.  The scalar-base encoding of this instruction
 // (`global_load_lds_dwordx4 v_off, s[base:base+1]`) was tried to save the 64-bit vector address arithmetic in front of it:
 // the kernel then aborts at its first launch (two runs, with and without an immediate offset), so the address stays a VGPR pair.
@@ -1885,13 +1848,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   constexpr int RBK = (SPW * 9 + 63) / 64;
   constexpr bool SHARE = hop4b_share_images(M);   // two link images per wave (LDS-DMA into the one not being read)
   constexpr bool PARTNER = SHARE && !CB;           // in-bundle backward links from the partner waves, U_3(x - 3) carried
-  constexpr bool ROWDMA = BCG_HOP4B_ROWDMA != 0;  // +x3 row (own sites + halo sites) by LDS-DMA into its slot
-  // PREO (with ROWDMA): the two rows that leave the bundle are loaded ONE STEP AHEAD into registers, so that the first
-  // three directions of a step wait for nothing and the step's only fresh data -- the +x3 row -- has them to arrive in
-  constexpr bool PREO = ROWDMA && BCG_HOP4B_PREO != 0;
-  constexpr bool PIPE = BCG_HOP4B_PIPE != 0 && hop4b_share_images(M) && !CB && !RESID && !ROWDMA;
+  constexpr bool PIPE = BCG_HOP4B_PIPE != 0 && hop4b_share_images(M) && !CB && !RESID;  // the software-pipelined step (below)
   constexpr int HB = 3 * M * 16;                  // bytes of one site = of one halo site
-  constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site  // in-bundle backward links from the partner waves' images (2 images per wave)
+  constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site
   constexpr int RB = 3 * M * 16;           // bytes of one site of a field
   constexpr int NH = (2 * M + 63) / 64;    // halo loads per lane and colour (1)
   static_assert(NH == 1, "halo sites fit one wave instruction per colour");
@@ -2271,7 +2230,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     // step, as many as the step has FMAs.
     // In capacity mode the ring-addressed side (the output of the plain hop, the input rows of the shifted one) keeps the
     // closed form; links, p and the other side are carried.
-    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB && !ROWDMA && !PREO;  // (PIPE below builds on it)
+    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB;  // (PIPE below builds on it)
     constexpr bool INCR_IN = INCR && !RING_IN, INCR_OUT = INCR && !RING_OUT;
     const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
     const char* ik_f = nullptr; const char* ik_l = nullptr; const char* ik_1 = nullptr; const char* ik_2 = nullptr;
@@ -2279,9 +2238,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     const char* iw_own = nullptr; const char* iw_lft = nullptr; const char* iw_rgt = nullptr;
     const char* io_1 = nullptr; const char* io_2 = nullptr; const char* ip_p = nullptr; char* ip_o = nullptr;
     int64_t id_l = 0, id_1 = 0, id_2 = 0, id_lft = 0, id_rgt = 0, id_o1 = 0, id_o2 = 0;
-#ifdef BCG_HOP4B_INCR_CHECK
-    bool incr_bad = false;
-#endif
     if (INCR) {
       const int lo = win.x3_lo, xn = lo + 1;
       const char* const ub_ = reinterpret_cast<const char*>(U);
@@ -2326,19 +2282,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       if (INCR_OUT) ip_o = reinterpret_cast<char*>(out) + c0s;
     }
     double2 o1[3], o2[3];
-    dv2 p1[3], p2[3];  // PREO: the rows of the NEXT step, loaded behind hipcc's back (ld_sv_async) and waited for by hand
-    if (PREO) {  // the first step's rows; every later step finds them loaded by the step before
-      const char* const q1 = row_o(k_o1, a_o1, s_o1, win.x3_lo, slot);
-      const char* const q2 = row_o(k_o2, a_o2, s_o2, win.x3_lo, slot);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q1, voff, c * M * 16);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q2, voff, c * M * 16);
-      // retire them HERE: a load still pending at the loop's entry makes hipcc wait for it at its use in EVERY iteration
-      // (it cannot tell the first from the rest), i.e. for everything the iteration itself has issued by then
-      asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y), "+v"(o1[1].x), "+v"(o1[1].y), "+v"(o1[2].x), "+v"(o1[2].y));
-      asm volatile("" : "+v"(o2[0].x), "+v"(o2[0].y), "+v"(o2[1].x), "+v"(o2[1].y), "+v"(o2[2].x), "+v"(o2[2].y));
-    }
     // ---- PIPE: the software-pipelined step -------------------------------------------------------------------------------
     // What bounded the form below (profiles/r03_stencil_*): every wave of a block issued its ~21 vector-memory instructions
     // -- 6 of them LDS-DMAs, the costliest to issue -- in one burst right behind the step's barrier (2.6 k of a step's 9.7 k
@@ -2506,23 +2449,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       acc[r].x = fma(eta, t[r].x, acc[r].x);                                                                 \
       acc[r].y = fma(eta, t[r].y, acc[r].y);                                                                 \
     }                                                                                                        \
-    BCG_PIPE_GROUPS(LAST)                                                                                    \
   }
-// the order above, prescribed to the scheduler: 6 LDS reads, 24 FMAs, ... (BCG_HOP4B_LNKGRP=0: left to its heuristics)
-#ifndef BCG_HOP4B_LNKGRP
-#define BCG_HOP4B_LNKGRP 0
-#endif
-#if BCG_HOP4B_LNKGRP
-#define BCG_PIPE_GROUPS(LAST)                                   \
-  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);           \
-  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);           \
-  if (!(LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0); \
-  __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);
-#else
-#define BCG_PIPE_GROUPS(LAST)
-#endif
 // the partner waves' rows of this slice (x1 / x2 neighbours inside the bundle): read a direction ahead of their use
 #define BCG_LD_LP(LP, CP) { _Pragma("unroll") for (int c = 0; c < 3; ++c) LP[c] = (CP)[co + c * M]; }
 #define BCG_PIPE_PIN asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y))
@@ -2577,20 +2504,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           n2[2] = ld_sv_async<2 * M * 16>(a2, voff);
           asm volatile("; ASYNC_ISSUED n");
         }
-        // ---- T (tuning build): touch what the step after next will load from HBM -- measured slower (profiles/r04_stencil_pipe.txt)
-        int nT = 0;
-        if (BCG_HOP4B_TOUCH != 0 && INCR_IN && x3 + 2 < x3_end && x3 + 2 < L3) {
-          const unsigned junk = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave))) + 9 * 16;
-          constexpr int LR = SPW * RB / 128, LK = SPW * 36 * 16 / 128;  // lines of a wave's row / of its forward links
-          static_assert(LR + LK <= 64 && (SPW * RB) % 128 == 0 && (SPW * 36 * 16) % 128 == 0, "touch: one lane per line");
-          const char* const t1 = lane < LR ? ir_own + lane * 128 : ik_f + (lane - LR) * 128;
-          if (lane < LR + LK) glds4_touch(t1, junk);
-          nT = 1;
-          if (MODE != HOP_PLAIN) {
-            if (lane < LR) glds4_touch(ip_p + id_row + lane * 128, junk);
-            nT = 2;
-          }
-        }
         __builtin_amdgcn_sched_barrier(0);
         BCG_STAMPB(6)   // next rows issued
         if (e2) { BCG_PIPE_DIR(2, 0, q2, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
@@ -2599,7 +2512,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         __builtin_amdgcn_sched_barrier(0);
         BCG_STAMPB(7)   // direction 2
         // ---- the +x3 row has landed in Cn once at most E, C and D (and the touches) are outstanding
-        wait_vmcnt(nE + (more ? nC + nD : 0) + nT);
+        wait_vmcnt(nE + (more ? nC + nD : 0));
         BCG_STAMPB(8)   // wait for the +x3 row
 #pragma unroll
         for (int c = 0; c < 3; ++c) f3[c] = Cn[co + c * M];
@@ -2609,7 +2522,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #undef BCG_LD
 #undef BCG_FM
 #undef BCG_PIPE_DIR
-#undef BCG_PIPE_GROUPS
 #undef BCG_LD_LP
 #undef BCG_PIPE_PIN
 #undef BCG_PIPE_APART
@@ -2617,7 +2529,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         if (more) park_u3(x3 + 1);  // U_3(x - 3) of the next slice = U_3 of this one (ds_read / ds_write; the DMAs fill the rest)
         double2 tv[3], pw[3];
         if (MODE != HOP_PLAIN) {
-          wait_vmcnt((more ? nC + nD : 0) + nT);  // p
+          wait_vmcnt(more ? nC + nD : 0);  // p
           // The values are handed to hipcc as NEW registers written behind the wait (plain inputs, early-clobber outputs): with
           // the loaded registers as in-out operands of an empty asm the allocator may pick other registers for the operand
           // and copy -- i.e. read -- the loaded ones in FRONT of the wait (it did, for the rows below).
@@ -2642,7 +2554,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         BCG_STAMPB(10)  // U_3 carried, wait for p, output, stores
         // everything but the stores: the links and the next rows have landed before this wave reaches the barrier
         __builtin_amdgcn_sched_barrier(0);
-        if (BCG_HOP4B_TOUCH != 0) wait_vmcnt(nS + nT);  // (the touches stay in flight; everything older has landed)
         if (more) {
           asm volatile("s_waitcnt vmcnt(%24) ; ASYNC_RETIRE n\n\t"
                        "v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\tv_mov_b64 %2, %14\n\tv_mov_b64 %3, %15\n\tv_mov_b64 %4, %16\n\tv_mov_b64 %5, %17\n\t"
@@ -2650,11 +2561,10 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
                        : "=&v"(q1[0].x), "=&v"(q1[0].y), "=&v"(q1[1].x), "=&v"(q1[1].y), "=&v"(q1[2].x), "=&v"(q1[2].y),
                          "=&v"(q2[0].x), "=&v"(q2[0].y), "=&v"(q2[1].x), "=&v"(q2[1].y), "=&v"(q2[2].x), "=&v"(q2[2].y)
                        : "v"(n1[0].x), "v"(n1[0].y), "v"(n1[1].x), "v"(n1[1].y), "v"(n1[2].x), "v"(n1[2].y),
-                         "v"(n2[0].x), "v"(n2[0].y), "v"(n2[1].x), "v"(n2[1].y), "v"(n2[2].x), "v"(n2[2].y),
-                         "n"(BCG_HOP4B_TOUCH != 0 ? nS + 2 : nS)
+                         "v"(n2[0].x), "v"(n2[0].y), "v"(n2[1].x), "v"(n2[1].y), "v"(n2[2].x), "v"(n2[2].y), "n"(nS)
                        : "memory");
         } else {
-          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(nS) : "memory");  // (no touch is issued in a column's last two steps)
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(nS) : "memory");
         }
         if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
           __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2686,35 +2596,11 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         }
       }
       BCG_STAMPB(0)   // pacing wait of thread 0 (the other waves' share of it shows up in the barrier)
-#if !(defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 64))  // timing experiment: no barrier per step
       __syncthreads();  // row slot x3 & 1 (written in the previous step) is complete
-#endif
       BCG_STAMPB(1)   // barrier
       if (x3 + 1 < x3_end) {
         if (CB) dma_links_cb(x3 + 1);
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 16)  // timing experiment: no link DMAs in the steps
-        else if (SHARE) {}
-#endif
         else if (SHARE && INCR) {
-#ifdef BCG_HOP4B_INCR_CHECK  // test build: the carried addresses against the closed forms; a mismatch poisons the output
-          {
-            const int xn = x3 + 1;
-            const char* const ub_ = reinterpret_cast<const char*>(U);
-            const char* const ug_ = reinterpret_cast<const char*>(Ughost);
-            const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(xn) * S3;
-            const char* const cf = ub_ + sw0 * (36 * 16);
-            const char* cl;
-            if (!row_start) cl = ub_ + (sw0 - 1) * (36 * 16);
-            else if (!sp0) cl = ub_ + (sw0 + L0 - 1) * (36 * 16);
-            else cl = ug_ + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + L2 * xn))) * (9 * 16);
-            const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(xn) * s_b1;
-            const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(xn) * s_b2;
-            const char* const c1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
-            const char* const c2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
-            if (cf != ik_f || cl != ik_l || (!e1 && c1 != ik_1) || (!e2 && c2 != ik_2)) incr_bad = true;
-            ik_f = cf; ik_l = cl; ik_1 = c1; ik_2 = c2;
-          }
-#endif
           dma_links_at(x3 + 1, ik_f, ik_l, ik_1, ik_2);
           ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;
         }
@@ -2733,79 +2619,22 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       // -x3 neighbour: this wave's own row of slice x3 - 1, read back before the slot is overwritten below
 #pragma unroll
       for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; bk[3][c] = make_double2(v.x, v.y); }
-      if (ROWDMA) {
-        // The +x3 row goes straight into Cn by LDS-DMA, so the old contents must be in registers first (the operands make
-        // the compiler wait for the three reads).  Issued in FRONT of the step's ordinary loads: those return in issue
-        // order behind it, so "o1[0] has arrived" (below) means the row has landed.
-        asm volatile("" : "+v"(bk[3][0].x), "+v"(bk[3][0].y), "+v"(bk[3][1].x), "+v"(bk[3][1].y), "+v"(bk[3][2].x), "+v"(bk[3][2].y));
-        int kind, xs, gx3;
-        const char* own;
-        const char* lft;
-        const char* rgt;
-        slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
-        row_ptrs3(kind, xs, gx3, own, lft, rgt);
-        const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(Cn));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) glds16(own + fo + k * 1024, cn + HB + k * 1024);  // SPW sites = 3 KB at every width
-#pragma unroll
-        for (int k = 0; k < NHD; ++k)
-          if (lane * 16 + k * 1024 < HB) {
-            glds16(lft + fo + k * 1024, cn + k * 1024);
-            glds16(rgt + fo + k * 1024, cn + (SPW + 1) * HB + k * 1024);
-          }
-      }
       // ---- global loads of the step: the two rows that leave the bundle, the +x3 row with its halo, p
-      const bool more = x3 + 1 < x3_end;
-      const int slot_n = RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0;
-      if (PREO) {
-        if (more) {  // issued LAST among the step's loads and DMAs: nothing this step waits for is queued behind them
-          const char* const q1 = row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
-          const char* const q2 = row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
-          p1[0] = ld_sv_async<0>(q1, voff);
-          p1[1] = ld_sv_async<M * 16>(q1, voff);
-          p1[2] = ld_sv_async<2 * M * 16>(q1, voff);
-          p2[0] = ld_sv_async<0>(q2, voff);
-          p2[1] = ld_sv_async<M * 16>(q2, voff);
-          p2[2] = ld_sv_async<2 * M * 16>(q2, voff);
-        }
-      } else {
-#ifdef BCG_HOP4B_INCR_CHECK
-        if (INCR_IN) {
-          const char* const c1 = row_o(k_o1, a_o1, s_o1, x3, slot);
-          const char* const c2 = row_o(k_o2, a_o2, s_o2, x3, slot);
-          if (c1 != io_1 || c2 != io_2) incr_bad = true;
-          io_1 = c1; io_2 = c2;
-        }
-#endif
+      {
         const char* const q_o1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3, slot);
         const char* const q_o2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3, slot);
         if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 4)  // timing experiment: no loads of the rows that leave the bundle
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o1[c] = o2[c] = make_double2(c0 + reinterpret_cast<uintptr_t>(q_o1) * 1e-30, c0 + reinterpret_cast<uintptr_t>(q_o2) * 1e-30);
-#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) o1[c] = ld_sv(q_o1, voff, c * M * 16);
 #pragma unroll
         for (int c = 0; c < 3; ++c) o2[c] = ld_sv(q_o2, voff, c * M * 16);
-#endif
       }
       dv2 hv[3];
-      if (!ROWDMA) {
+      {
         int kind, xs, gx3;
         const char* own;
         const char* hal;
         if (INCR_IN && x3 + 1 < L3) {  // a slice of `in`: carried along; the column's last +x3 row wraps or is a ghost face
-#ifdef BCG_HOP4B_INCR_CHECK
-          {
-            const char* co_;
-            const char* cl_;
-            const char* cr_;
-            row_ptrs3(0, x3 + 1, x3 + 1, co_, cl_, cr_);
-            if (co_ != ir_own || cl_ != ir_lft || cr_ != ir_rgt) incr_bad = true;
-            ir_own = co_; ir_lft = cl_; ir_rgt = cr_;
-          }
-#endif
           own = ir_own;
           hal = (hs ? ir_rgt : ir_lft) + hj * 16;
           ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
@@ -2816,29 +2645,13 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           slice_of(x3 + 1, RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0, kind, xs, gx3);
           row_ptrs(kind, xs, gx3, own, hal);
         }
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 8)  // timing experiment: no load of the +x3 row and its halo sites
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          f[3][c] = make_double2(c0 + reinterpret_cast<uintptr_t>(own) * 1e-30, c0);
-          hv[c] = dv2{c0 + reinterpret_cast<uintptr_t>(hal) * 1e-30, c0};
-        }
-#else
 #pragma unroll
         for (int c = 0; c < 3; ++c) f[3][c] = ld_sv(own, voff, c * M * 16);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           if (halo_lane) hv[c] = *reinterpret_cast<const dv2*>(hal + c * M * 16);
-#endif
       }
       const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
-#ifdef BCG_HOP4B_INCR_CHECK
-      if (INCR) {
-        if (ip_p != reinterpret_cast<const char*>(p) + crow_site * RB) incr_bad = true;
-        if (INCR_OUT && ip_o != reinterpret_cast<char*>(out) + crow_site * RB) incr_bad = true;
-        ip_p = reinterpret_cast<const char*>(p) + crow_site * RB;
-        if (INCR_OUT) ip_o = reinterpret_cast<char*>(out) + crow_site * RB;
-      }
-#endif
       const char* const prow = INCR ? ip_p : reinterpret_cast<const char*>(p) + crow_site * RB;
       char* const orow = INCR_OUT ? ip_o : reinterpret_cast<char*>(out) + (RING_OUT ? static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3 : crow_site) * RB;
       if (INCR) ip_p += id_row;
@@ -2901,19 +2714,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 #pragma unroll
       for (int mu = 0; mu < 4; ++mu) {
-        BCG_HOP4B_DIR_BARRIER;
-        if (ROWDMA && mu == 3) {
-          // o1[0] is the oldest ordinary load of the step and younger than the row DMAs: once it is in its register the row
-          // is in Cn; the clobber keeps the compiler from reading Cn earlier (or re-using bk[3], read from the same address)
-          // (PREO: the oldest load issued BEHIND the row DMAs is the next step's o1n[0]; the last step of a column has none)
-          // PREO: behind the row DMAs come at most the six loads of the next step's rows (and, wherever hipcc put them, the
-          // three of p: then this waits for three more than it must) -- none in the last step of a column
-          if (!PREO) asm volatile("" : "+v"(o1[0].x), "+v"(o1[0].y) : : "memory");
-          else if (more) asm volatile("s_waitcnt vmcnt(6)" : : : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { const dv2 v = Cn[co + c * M]; f[3][c] = make_double2(v.x, v.y); }
-        }
+        __builtin_amdgcn_sched_barrier(0);
         const int par = mu == 0 ? 0 : (mu == 1 ? par1 : (mu == 2 ? par2 : par3));
         const double eta = (par & 1) ? -1.0 : 1.0;
         const dv2* uf = Lf + (sw + 1) * 36 + mu * 9;
@@ -2921,16 +2722,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
                                 : (mu == 1 ? ub1 : (mu == 2 ? ub2 : Lb + (2 * SPW + sw) * 9));
         // acc += eta (U_mu(x) F - U_mu(x - mu)^dagger B): F the forward neighbour, B the backward one.  A macro, not a lambda:
         // with a lambda the form with the fused product reloaded 130 spilled SGPRs per step instead of 40.
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 2)  // ... no link reads at all: a value the compiler cannot fold
-#define BCG_LINK_F(k, r) dv2{c0 + k, c0 - r}
-#else
 #define BCG_LINK_F(k, r) uf[(k) * 3 + (r)]
-#endif
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 1)  // timing experiment (wrong results): half the link reads from LDS
-#define BCG_LINK_B(k, r, u) (u)
-#else
 #define BCG_LINK_B(k, r, u) ub[(r) * 3 + (k)]
-#endif
 #define BCG_DIR_TERM(F, B)                                                                                   \
   {                                                                                                          \
     double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
@@ -2981,7 +2774,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         else park_links(x3 + 1, false);
       }
       // park the +x3 row (own sites and halo) as the next step's centre row
-      if (!ROWDMA) {
+      {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           dv2 v;
@@ -2991,26 +2784,13 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           if (halo_lane) Cn[ho + c * M] = hv[c];
         }
       }
-      if (PREO && more) {
-        // the next step's rows have had the whole step to arrive; no store of THIS step is queued yet, so vmcnt(0) waits
-        // for loads only (and for the previous step's stores, a step old).  The operands keep every use behind the wait.
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p1[0]), "+v"(p1[1]), "+v"(p1[2]), "+v"(p2[0]), "+v"(p2[1]), "+v"(p2[2]));
-      }
       double2 tv[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (MODE == HOP_PLAIN) tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
         else tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-#ifdef BCG_HOP4B_INCR_CHECK
-        if (incr_bad) tv[r] = make_double2(__builtin_nan(""), __builtin_nan(""));
-#endif
         if (RESID) tv[r] = make_double2(tv[r].x - bv[r].x, tv[r].y - bv[r].y);  // AX -= B (test/solvers.cpp:109)
-        else if (BCG_HOP4B_STORE_SC1) st_sc1(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
-#if defined(BCG_HOP4B_EXPERIMENT) && (BCG_HOP4B_EXPERIMENT & 32)  // timing experiment: no output stores
-        else if (tv[r].x == 1.2345e300) st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
-#else
         else st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16), tv[r]);
-#endif
       }
       if (GRAM) {
 #pragma unroll
@@ -3026,13 +2806,6 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
       }
       if (RING) slot = slot + 1 == win.ring ? 0 : slot + 1;
-      if (PREO && more) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          o1[c] = make_double2(p1[c].x, p1[c].y);
-          o2[c] = make_double2(p2[c].x, p2[c].y);
-        }
-      }
       BCG_STAMPB(7)   // tail: links/row parked, p, stores, pacing counters
     }
   }
