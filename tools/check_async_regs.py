@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Build-time check for k_hop4b's hand-waited global loads (ld_sv_async in the PIPE schedule).
+"""Build-time check for the hand-waited global loads of k_hop4b's PIPE schedule and of k_hop5 (ld_sv_async).
 
 hipcc does not see these loads (inline asm): it believes their destination registers hold the values from the moment of
 issue.  Correctness therefore needs that between a group's ISSUE and the hand-written wait that RETIRES it no instruction
 on the path reads, copies or overwrites those registers.  The kernel brackets every group with asm comments
     ; ASYNC_ISSUE <tag>  ...loads...  ; ASYNC_ISSUED <tag>      and marks the point behind the retiring wait     ; ASYNC_RETIRE <tag>
-and this script walks the device assembly of every k_hop4b instantiation from ISSUED along the control flow (unconditional
+and this script walks the device assembly of every k_hop4b / k_hop5 instantiation from ISSUED along the control flow (unconditional
 branches are followed, conditional ones fork) to the RETIRE marker or to a hand-written end-of-step wait (vmcnt(3) or
 less): no instruction on any such path may name a destination register of the group, and every path must end in one.
 
@@ -16,10 +16,12 @@ import sys
 
 
 def regs_of(text):
+    """registers an instruction names: architectural VGPR n as n, accumulation register n as 1000 + n"""
     used = set()
-    for a, b in re.findall(r'\bv\[(\d+):(\d+)\]', text):
-        used |= set(range(int(a), int(b) + 1))
-    used |= {int(r) for r in re.findall(r'\bv(\d+)\b', text)}
+    for kind, base in (('v', 0), ('a', 1000)):
+        for a, b in re.findall(r'\b%s\[(\d+):(\d+)\]' % kind, text):
+            used |= set(range(base + int(a), base + int(b) + 1))
+        used |= {base + int(r) for r in re.findall(r'\b%s(\d+)\b' % kind, text)}
     return used
 
 
@@ -27,7 +29,7 @@ def main(path):
     txt = open(path).read()
     ok = True
     seen = 0
-    for m in re.finditer(r'^(_ZN3bcg\S*k_hop4b[^:\s]*):[^\n]*\n(.*?)s_endpgm', txt, re.S | re.M):
+    for m in re.finditer(r'^(_ZN3bcg\S*k_hop(?:4b|5)[^:\s]*):[^\n]*\n(.*?)s_endpgm', txt, re.S | re.M):
         lines = m.group(2).split('\n')
         label = {l.split(':')[0]: i for i, l in enumerate(lines) if re.match(r'^\.LBB\w+:', l)}
         starts = [(i, l.split('ASYNC_ISSUE ')[1].split()[0]) for i, l in enumerate(lines) if 'ASYNC_ISSUE ' in l]
@@ -36,9 +38,10 @@ def main(path):
             j = i + 1
             regs = set()
             while j < len(lines) and f'ASYNC_ISSUED {tag}' not in lines[j]:
-                d = re.search(r'global_load_dwordx4\s+v\[(\d+):(\d+)\]', lines[j])
+                d = re.search(r'global_load_dwordx4\s+([va])\[(\d+):(\d+)\]', lines[j])
                 if d:
-                    regs |= set(range(int(d.group(1)), int(d.group(2)) + 1))
+                    base = 1000 if d.group(1) == 'a' else 0
+                    regs |= set(range(base + int(d.group(2)), base + int(d.group(3)) + 1))
                 j += 1
             todo, done, bad, reached, lost = [j + 1], set(), [], 0, 0
             why = []
@@ -85,7 +88,7 @@ def main(path):
             # statically infeasible paths (the issue sits under `more`, some waits under `!more`) may wander past the loop: they are
             # walked and checked like the others; what must hold is that NO walked instruction touches the registers
             good = reached > 0 and not bad and regs
-            print(m.group(1)[28:62], f'group {tag}: v{min(regs)}..v{max(regs)}, {walked} instructions walked, paths to the retire:',
+            print(m.group(1)[28:62], f'group {tag}: {len(regs)} registers ({"AGPRs" if min(regs) >= 1000 else "VGPRs"} from {min(regs) % 1000}), {walked} instructions walked, paths to the retire:',
                   reached, 'lost:', lost, 'touched in between:', len(bad))
             for b_ in bad[:6]:
                 print('     ', b_)
