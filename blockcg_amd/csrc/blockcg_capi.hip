@@ -525,16 +525,12 @@ int boundary_tile_list(bcg_context* c, int spb, const int** list, int* n) {
 
 // Profiling only: count the launches of each form of the stencil kernel ("stencil_form_k_hop4c" ...), so that tests
 // and tuning runs can tell which one a lattice shape gets.
-void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win, bool plain = false, bool gram = false) {
+void note_stencil_form(bcg_context* c, int m, int tile_class, const bcg::HopWindow& win, bool plain = false) {
   if (!c->profiling) return;
-  static const char* names[] = {"stencil_form_general", "stencil_form_k_hop4", "stencil_form_k_hop4c", "stencil_form_k_hop4b",
-                                "stencil_form_k_hop5"};
+  static const char* names[] = {"stencil_form_general", "stencil_form_k_hop4", "stencil_form_k_hop4c", "stencil_form_k_hop4b"};
   int form = bcg::hop_kernel_form(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win);
   if (form == 2 && bcg::hop_uses_bundle(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win, plain)) form = 3;
-  if (form == 3 && bcg::hop_uses_hop5(m, c->lat, kFastBlocks, c->hop_tune, tile_class, win, gram,
-                                      plain ? bcg::HOP_PLAIN : bcg::HOP_SHIFTED))
-    form = 4;
-  if (form >= 0 && form <= 4) c->prof[names[form]].count += 1;
+  if (form >= 0 && form <= 3) c->prof[names[form]].count += 1;
 }
 
 // out = D in  (HOP_PLAIN)  or  out = c0*p - D in  (HOP_SHIFTED).  With gram_blocks != nullptr (m = 16 fast
@@ -590,7 +586,7 @@ int hop(bcg_context* c, const bcg_gauge* g, bcg_field* out, const bcg_field* in,
   }
   BCG_TRY(halo_field(c, in));
   if (fast) {
-    note_stencil_form(c, m, 0, bcg::HopWindow(), mode == bcg::HOP_PLAIN, gram);
+    note_stencil_form(c, m, 0, bcg::HopWindow(), mode == bcg::HOP_PLAIN);
     bcg::HopTuning tune = c->hop_tune;
     // one whole launch of a column form: the kernel's last blocks sum the Gram partials themselves (no reduction launch)
     const bool fold = gram && gram_folded && bcg::hop_folds_gram(m, c->lat, kFastBlocks, tune, bcg::HopWindow());
@@ -1216,7 +1212,6 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HOP_SYNC_LIMIT")) c->hop_tune.sync.limit_ticks = std::atoi(e);
   if (const char* e = std::getenv("BCG_HOP_COLUMN")) c->hop_tune.sync.column_walk = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BUNDLE")) c->hop_tune.sync.bundle_walk = std::atoi(e);
-  if (const char* e = std::getenv("BCG_HOP5")) c->hop_tune.hop5 = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_BUNDLE_SYNC")) c->hop_tune.sync.bundle_window = std::atoi(e);
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
   if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)

@@ -113,14 +113,6 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
-// The same into ACCUMULATION registers (k_hop5: one wave per SIMD, 512 registers; hipcc fills the 256 architectural ones and
-// would park a long-lived hand-waited destination in an AGPR itself -- by copying it, i.e. reading it, before it has arrived)
-template <int IMM>
-__device__ __forceinline__ dv2 ld_sv_async_a(const char* sbase, unsigned voff) {
-  dv2 r;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(r) : "v"(voff), "s"(sbase), "n"(IMM));
-  return r;
-}
 // link loads of the stencil (non-temporal loads were tried here: 13 % fewer L2 misses, no time gained)
 __device__ __forceinline__ dv2 ld_link(const dv2* p) { return *p; }
 __device__ __forceinline__ void st_nt(double2* p, double2 v) {
@@ -2841,523 +2833,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   hop4b_body<M, MODE, GRAM, RING, CB>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_hop5: the bundle sweep of k_hop4b (PIPE schedule) with TWO right-hand sides per lane -- m = 16, forms without the fused
-// Gram product (tmp = D P of the operator, the plain applications).
-//
-// What the stamps of k_hop4b's pipelined step say (profiles/r04_stencil_pipe.txt): the memory waits are 8 % of a step; the
-// step is the instruction stream of the wave itself -- per 288 FMAs a lane issues ~90 LDS reads (72 of them link entries,
-// each feeding 4 FMAs), ~20 vector-memory instructions at 50-130 cycles apiece, address bookkeeping, a barrier -- with two
-// waves per SIMD to overlap them.  Here a site has 8 lanes and a lane carries right-hand sides 2 jp and 2 jp + 1, so a wave
-// covers 8 consecutive x0 sites (tile 8 x 2 x 2 per block) and every link entry read from LDS feeds 8 FMAs; the
-// per-step instructions that do not scale with the sites (barrier, bookkeeping, the issue of a DMA) are spread over twice
-// the sites.  Rows and link images of the wider tile take 130.6 KB of LDS: ONE block of four waves per CU, one wave per
-// SIMD with the whole register file -- the next step's rows that leave the bundle, both right-hand sides' operands and
-// the links read two units ahead all stay in registers (no spills at 512).
-// Same tile order / XCD patches / pacing / windows / ring addressing / ghost faces as k_hop4b, same FMAs in the same order
-// per (site, right-hand side): bit-identical output.  lane = (site sw = lane >> 3, pair jp = lane & 7).
-// ---------------------------------------------------------------------------------------------------
-template <int MODE, bool RING>
-__device__ __forceinline__ void hop5_body(const LatticeDev& lat, const double2* __restrict__ U,
-                                          const double2* __restrict__ Ughost, const double2* __restrict__ in,
-                                          const double2* __restrict__ ghost, double2* __restrict__ out,
-                                          const double2* __restrict__ p, double c0, double2* __restrict__ partials,
-                                          const HopWalk& hw, const HopWindow& win) {
-  static_assert(MODE == HOP_PLAIN || MODE == HOP_SHIFTED, "plain and shifted forms");
-  constexpr int M = 16, SPW = 8, NW = 4;
-  constexpr bool RING_OUT = RING && MODE == HOP_PLAIN, RING_IN = RING && MODE == HOP_SHIFTED;
-  constexpr int CS = (SPW + 2) * 3 * M;        // one wave's row slot: halo site, 8 sites, halo site (complex numbers)
-  constexpr int NFW = (SPW + 1) * 36;          // link image: record of the site to the left (U_0 only), forward links
-  constexpr int NBW = 3 * SPW * 9;             // backward links of directions 1, 2 (rows outside the bundle) and 3 (carried)
-  constexpr int LSTAGE = NFW + NBW;
-  constexpr int RFW = (SPW * 36 + 63) / 64;    // 5 DMA instructions for the forward links
-  constexpr int RBK = (SPW * 9 + 63) / 64;     // 2 for a direction's backward links
-  constexpr int RB = 3 * M * 16, HB = RB;      // bytes of a site
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int e1 = wave & 1, e2 = wave >> 1;
-  dv2* const Cbase = reinterpret_cast<dv2*>(smem);             // [2 slots][4 waves][CS]
-  dv2* const Lbase = Cbase + 2 * NW * CS;                      // [2 images][4 waves][LSTAGE]
-  auto image = [&](int x3, int w) __attribute__((always_inline)) { return Lbase + ((x3 & 1) * NW + w) * LSTAGE; };
-  const int sw = lane >> 3, jp = lane & 7;
-  const unsigned voff = static_cast<unsigned>((sw * 3 * M + 2 * jp) * 16);  // (site sw, colour 0, rhs 2 jp) in a row; rhs 2 jp + 1: + 16
-  const int co = (sw + 1) * 3 * M + 2 * jp;                                  // the same element in a row slot
-  const unsigned fo = static_cast<unsigned>(lane) * 16;
-  const int L0 = lat.L[0], L1 = lat.L[1], L2 = lat.L[2], L3 = lat.L[3];
-  const int S1 = L0, S2 = L0 * L1, S3 = L0 * L1 * L2;
-  const int sp0 = lat.split[0], sp1 = lat.split[1], sp2 = lat.split[2], sp3 = lat.split[3];
-  const int gm0 = static_cast<int>(lat.ghost_off[0][0]), gp0 = static_cast<int>(lat.ghost_off[0][1]);
-  const int gm1 = static_cast<int>(lat.ghost_off[1][0]), gp1 = static_cast<int>(lat.ghost_off[1][1]);
-  const int gm2 = static_cast<int>(lat.ghost_off[2][0]), gp2 = static_cast<int>(lat.ghost_off[2][1]);
-  const int gm3 = static_cast<int>(lat.ghost_off[3][0]), gp3 = static_cast<int>(lat.ghost_off[3][1]);
-  const int og0 = lat.origin[0], og1 = lat.origin[1], og2 = lat.origin[2];
-  const char* const inb = reinterpret_cast<const char*>(in);
-  const char* const ghb = reinterpret_cast<const char*>(ghost);
-  const char* const ub_ = reinterpret_cast<const char*>(U);
-  const char* const ug_ = reinterpret_cast<const char*>(Ughost);
-  // backward-link element e = lane + 64 k (site e / 9, entry e % 9): byte offset in a row of 36-entry site records
-  // (bo_f) and in a packed ghost face (bo_g)
-  const unsigned bo_f0 = static_cast<unsigned>((lane / 9) * 36 + lane % 9) * 16;
-  const unsigned bo_f1 = static_cast<unsigned>(((lane + 64) / 9) * 36 + (lane + 64) % 9) * 16;
-  const unsigned bo_g0 = static_cast<unsigned>(lane) * 16, bo_g1 = static_cast<unsigned>(lane + 64) * 16;
-
-  const int r0 = hw.p0 / SPW, r1 = hw.p1 / 2, r4 = L0 / hw.p0, r5 = L1 / hw.p1, r6 = L2 / hw.p2;
-  const int cls = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int d0 = idx % r0, d1 = (idx / r0) % r1, d2 = idx / (r0 * r1);
-  const int ppc = (r4 * r5 * r6) >> 3;
-  const int x3_end = win.x3_lo + win.x3_n;
-#ifdef BCG_HOP4B_STAMPS  // diagnostic build (tools/hop_stamps.py hop5): where a step's cycles go, summed per wave
-  long long seg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = __builtin_amdgcn_s_memtime();
-#define BCG_STAMP5(i)                                  \
-  {                                                    \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    const long long t_ = __builtin_amdgcn_s_memtime(); \
-    seg[i] += t_ - tlast;                              \
-    tlast = t_;                                        \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  }
-#else
-#define BCG_STAMP5(i)
-  (void)partials;
-#endif
-  bool pace = true;
-  const unsigned zero_rt = static_cast<unsigned>(hw.sync_window) >> 30;
-  unsigned seen1 = 0, seen2 = 0;
-  int seen1_idx = -1, seen2_idx = -1;
-  const unsigned per = gridDim.x >> 3;
-
-  for (int pk = 0; pk < ppc; ++pk) {
-    const int pi = cls * ppc + pk;
-    const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
-    const int x0b = (d4 * r0 + d0) * SPW, x1 = d5 * hw.p1 + d1 * 2 + e1, x2 = d6 * hw.p2 + d2 * 2 + e2;
-    const int col = x0b + L0 * (x1 + L1 * x2);
-    const int vs0 = pk * win.x3_n - win.x3_lo;
-    // the row of this wave that leaves the bundle in direction 1 (forward if e1, else backward) and in direction 2; the
-    // backward LINK rows of those directions: site at x3 = 0, site stride per slice, field (false) or ghost face (true)
-#define BCG5_ROW(FWD, XM, LM, SM, SPM, GMN, GPL, FIDX, FSTR, AO, SO, KO)                                   \
-  int AO, SO;                                                                                             \
-  bool KO;                                                                                                \
-  if (FWD) {                                                                                              \
-    if ((XM) + 1 < (LM)) { AO = col + (SM); SO = S3; KO = false; }                                        \
-    else if (!(SPM)) { AO = col - ((LM) - 1) * (SM); SO = S3; KO = false; }                               \
-    else { AO = (GPL) + (FIDX); SO = (FSTR); KO = true; }                                                 \
-  } else {                                                                                                \
-    if ((XM) > 0) { AO = col - (SM); SO = S3; KO = false; }                                               \
-    else if (!(SPM)) { AO = col + ((LM) - 1) * (SM); SO = S3; KO = false; }                               \
-    else { AO = (GMN) + (FIDX); SO = (FSTR); KO = true; }                                                 \
-  }
-    BCG5_ROW(e1, x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_o1, s_o1, k_o1)
-    BCG5_ROW(e2, x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_o2, s_o2, k_o2)
-    BCG5_ROW(false, x1, L1, S1, sp1, gm1, gp1, x0b + L0 * x2, L0 * L2, a_b1, s_b1, k_b1)
-    BCG5_ROW(false, x2, L2, S2, sp2, gm2, gp2, x0b + L0 * x1, L0 * L1, a_b2, s_b2, k_b2)
-#undef BCG5_ROW
-    const bool row_end = x0b + SPW == L0, row_start = x0b == 0;
-    const unsigned bo1_0 = k_b1 ? bo_g0 : bo_f0, bo1_1 = k_b1 ? bo_g1 : bo_f1;
-    const unsigned bo2_0 = k_b2 ? bo_g0 : bo_f0, bo2_1 = k_b2 ? bo_g1 : bo_f1;
-
-    // link DMAs of slice x3 into image(x3): forward links and the left site's U_0, the backward links of the rows outside
-    // the bundle; first: U_3(x - 3) too (a column's prologue; afterwards it is carried from the previous image)
-    auto dma_links = [&](int x3, const char* fsrc, const char* lsrc, const char* q1, const char* q2, bool first) __attribute__((always_inline)) {
-      const unsigned img = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3, wave)));
-#pragma unroll
-      for (int k = 0; k < RFW; ++k)
-        if (lane + 64 * k < SPW * 36) glds16_link(fsrc + fo + k * 1024, img + (36 + 64 * k) * 16);
-      if (lane < 9) glds16_link(lsrc + fo, img);
-      if (!e1) {
-        glds16_link(q1 + bo1_0, img + NFW * 16);
-        if (lane + 64 < SPW * 9) glds16_link(q1 + bo1_1, img + (NFW + 64) * 16);
-      }
-      if (!e2) {
-        glds16_link(q2 + bo2_0, img + (NFW + SPW * 9) * 16);
-        if (lane + 64 < SPW * 9) glds16_link(q2 + bo2_1, img + (NFW + SPW * 9 + 64) * 16);
-      }
-      if (first) {
-        const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
-        const char* q3;
-        bool k_b3 = false;
-        if (x3 > 0) q3 = ub_ + ((sw0 - S3) * 4 + 3) * (9 * 16);
-        else if (!sp3) q3 = ub_ + ((sw0 + static_cast<int64_t>(L3 - 1) * S3) * 4 + 3) * (9 * 16);
-        else { q3 = ug_ + (static_cast<int64_t>(gm3) + col) * (9 * 16); k_b3 = true; }
-        glds16_link(q3 + (k_b3 ? bo_g0 : bo_f0), img + (NFW + 2 * SPW * 9) * 16);
-        if (lane + 64 < SPW * 9) glds16_link(q3 + (k_b3 ? bo_g1 : bo_f1), img + (NFW + 2 * SPW * 9 + 64) * 16);
-      }
-    };
-    auto link_ptrs = [&](int x3, const char*& fsrc, const char*& lsrc, const char*& q1, const char*& q2) __attribute__((always_inline)) {
-      const int64_t sw0 = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
-      fsrc = ub_ + sw0 * (36 * 16);
-      if (!row_start) lsrc = ub_ + (sw0 - 1) * (36 * 16);
-      else if (!sp0) lsrc = ub_ + (sw0 + L0 - 1) * (36 * 16);
-      else lsrc = ug_ + (static_cast<int64_t>(gm0) + (x1 + L1 * (x2 + static_cast<int64_t>(L2) * x3))) * (9 * 16);
-      const int64_t n1 = static_cast<int64_t>(a_b1) + static_cast<int64_t>(x3) * s_b1;
-      const int64_t n2 = static_cast<int64_t>(a_b2) + static_cast<int64_t>(x3) * s_b2;
-      q1 = k_b1 ? ug_ + n1 * (9 * 16) : ub_ + (n1 * 4 + 1) * (9 * 16);
-      q2 = k_b2 ? ug_ + n2 * (9 * 16) : ub_ + (n2 * 4 + 2) * (9 * 16);
-    };
-    // U_3(x - 3) of slice x3 = U_3 of the wave's own sites in image(x3 - 1): copied into image(x3)
-    auto park_u3 = [&](int x3) __attribute__((always_inline)) {
-      const dv2* const Lo = image(x3 - 1, wave);
-      dv2* const Ln = image(x3, wave);
-      Ln[NFW + 2 * SPW * 9 + lane] = Lo[36 + 27 + (bo_f0 >> 4)];
-      if (lane + 64 < SPW * 9) Ln[NFW + 2 * SPW * 9 + lane + 64] = Lo[36 + 27 + (bo_f1 >> 4)];
-    };
-    // row `xs` of this wave's column as stored (slice index or ring slot; gx3 its true index for the ghost faces), or a
-    // ghost face of direction 3: base pointers of the own sites and of the left / right halo site
-    auto row_ptrs = [&](int kind, int xs, int gx3, const char*& own, const char*& lft, const char*& rgt) __attribute__((always_inline)) {
-      if (kind == 0) {
-        own = inb + (static_cast<int64_t>(col) + static_cast<int64_t>(xs) * S3) * RB;
-        const int64_t f0i = x1 + L1 * (x2 + static_cast<int64_t>(L2) * gx3);
-        if (!row_start) lft = own - RB;
-        else if (!sp0) lft = own + static_cast<int64_t>(L0 - 1) * RB;
-        else lft = ghb + (static_cast<int64_t>(gm0) + f0i) * RB;
-        if (!row_end) rgt = own + static_cast<int64_t>(SPW) * RB;
-        else if (!sp0) rgt = own - static_cast<int64_t>(L0 - SPW) * RB;
-        else rgt = ghb + (static_cast<int64_t>(gp0) + f0i) * RB;
-      } else {
-        own = ghb + (static_cast<int64_t>(kind == 1 ? gp3 : gm3) + col) * RB;
-        lft = rgt = own;  // any valid address: such a row is never used as a centre row
-      }
-    };
-    auto slice_of = [&](int g, int slot_g, int& kind, int& xs, int& gx3) __attribute__((always_inline)) {
-      if (g >= 0 && g < L3) { kind = 0; xs = RING_IN ? slot_g : g; gx3 = g; }
-      else if (g < 0) {
-        if (!sp3) { kind = 0; xs = RING_IN ? win.ring - 1 : L3 - 1; gx3 = L3 - 1; }
-        else { kind = 2; xs = 0; gx3 = 0; }
-      } else {
-        if (!sp3) { kind = 0; xs = 0; gx3 = 0; }
-        else { kind = 1; xs = 0; gx3 = 0; }
-      }
-    };
-    auto row_o = [&](bool k_o, int a_o, int s_o, int x3v, int slotv) __attribute__((always_inline)) {
-      return k_o ? ghb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(x3v) * s_o) * RB
-                 : inb + (static_cast<int64_t>(a_o) + static_cast<int64_t>(RING_IN ? slotv : x3v) * s_o) * RB;
-    };
-    // a row (own sites and halo sites) by LDS-DMA into a slot
-    auto dma_row = [&](dv2* slot_ptr, const char* own, const char* lft, const char* rgt) __attribute__((always_inline)) {
-      const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(slot_ptr));
-#pragma unroll
-      for (int k = 0; k < SPW * RB / 1024; ++k) glds16_link(own + fo + k * 1024, cn + HB + k * 1024);
-      if (lane * 16 < HB) {
-        glds16_link(lft + fo, cn);
-        glds16_link(rgt + fo, cn + (SPW + 1) * HB);
-      }
-    };
-
-    // ---- column prologue: slices x3_lo (centre of the first step) and x3_lo - 1 (its -x3 neighbour), the first links
-    __syncthreads();  // every wave has left the previous column
-    int slot = RING ? win.x3_lo % win.ring : 0;
-    const int lo = win.x3_lo;
-    {
-      int kind, xs, gx3;
-      const char *own, *lft, *rgt;
-      slice_of(lo, slot, kind, xs, gx3);
-      row_ptrs(kind, xs, gx3, own, lft, rgt);
-      dma_row(Cbase + ((lo & 1) * NW + wave) * CS, own, lft, rgt);
-      slice_of(lo - 1, RING ? (slot == 0 ? win.ring - 1 : slot - 1) : 0, kind, xs, gx3);
-      row_ptrs(kind, xs, gx3, own, lft, rgt);
-      dma_row(Cbase + (((lo + 1) & 1) * NW + wave) * CS, own, lft, rgt);
-      const char *fs, *ls, *q1, *q2;
-      link_ptrs(lo, fs, ls, q1, q2);
-      dma_links(lo, fs, ls, q1, q2, true);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before the first step's barrier
-    }
-    // addresses carried along the column (all linear in x3 where the whole lattice is addressed)
-    constexpr bool INCR_IN = !RING_IN, INCR_OUT = !RING_OUT;
-    const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
-    const int64_t face = static_cast<int64_t>(L1) * L2;
-    const char *ik_f, *ik_l, *ik_1, *ik_2;
-    link_ptrs(lo + 1, ik_f, ik_l, ik_1, ik_2);
-    const int64_t id_l = (row_start && sp0) ? face * (9 * 16) : id_f;
-    const int64_t id_1 = static_cast<int64_t>(s_b1) * (k_b1 ? 9 * 16 : 36 * 16), id_2 = static_cast<int64_t>(s_b2) * (k_b2 ? 9 * 16 : 36 * 16);
-    const char *ir_own = nullptr, *ir_lft = nullptr, *ir_rgt = nullptr, *iw_own = nullptr, *iw_lft = nullptr, *iw_rgt = nullptr;
-    int64_t id_lft = id_row, id_rgt = id_row;
-    if (INCR_IN) {
-      row_ptrs(0, lo + 1, lo + 1, ir_own, ir_lft, ir_rgt);
-      if (row_start && sp0) id_lft = face * RB;
-      if (row_end && sp0) id_rgt = face * RB;
-      int kind, xs, gx3;
-      slice_of(L3, 0, kind, xs, gx3);  // the +x3 row of the column's last slice: slice 0 again, or the +x3 ghost face
-      row_ptrs(kind, xs, gx3, iw_own, iw_lft, iw_rgt);
-    }
-    const char* io_1 = INCR_IN ? row_o(k_o1, a_o1, s_o1, lo, 0) : nullptr;
-    const char* io_2 = INCR_IN ? row_o(k_o2, a_o2, s_o2, lo, 0) : nullptr;
-    const int64_t id_o1 = static_cast<int64_t>(s_o1) * RB, id_o2 = static_cast<int64_t>(s_o2) * RB;
-    const int64_t c0s = (static_cast<int64_t>(col) + static_cast<int64_t>(lo) * S3) * RB;
-    const char* ip_p = reinterpret_cast<const char*>(p) + c0s;
-    char* ip_o = INCR_OUT ? reinterpret_cast<char*>(out) + c0s : nullptr;
-
-    dv2 q1v[3][2], q2v[3][2];  // rows that leave the bundle: this step's (complete)
-    {
-      const char* const a1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, lo, slot);
-      const char* const a2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, lo, slot);
-      if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const double2 v1 = ld_sv(a1, voff, c * M * 16 + h * 16), v2 = ld_sv(a2, voff, c * M * 16 + h * 16);
-          q1v[c][h] = dv2{v1.x, v1.y};
-          q2v[c][h] = dv2{v2.x, v2.y};
-        }
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        asm volatile("" : "+v"(q1v[c][0]), "+v"(q1v[c][1]), "+v"(q2v[c][0]), "+v"(q2v[c][1]));
-    }
-    constexpr int nE = MODE == HOP_PLAIN ? 0 : 6, nD = 12, nS = 6;
-    const int nC = RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);
-
-    for (int x3 = lo; x3 < x3_end; ++x3) {
-      const bool more = x3 + 1 < x3_end;
-      const int slot_n = RING ? (slot + 1 == win.ring ? 0 : slot + 1) : 0;
-      const int step_n = vs0 + x3;
-      if (hw.sync != nullptr && tid == 0 && pace) {  // pacing: all blocks of this XCD class within `sync_window` slices
-        const int need = step_n - hw.sync_window;
-        const unsigned known = seen2_idx == need ? seen2 : (seen1_idx == need ? seen1 : 0u);
-        if (need >= 0 && known < per) {
-          unsigned* ctr = hw.sync + cls * hw.sync_stride + need;
-          const long long t0 = wall_clock64();
-          while (read_counter(ctr, zero_rt) < per) {
-            if (wall_clock64() - t0 > hw.sync_limit) {
-              pace = false;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-      }
-      BCG_STAMP5(0)   // loop overhead, pacing wait of thread 0
-      __syncthreads();  // row slot x3 & 1 and link image x3 & 1 (filled during the previous step) are complete
-      BCG_STAMP5(1)   // barrier
-      const dv2* const Lf = image(x3, wave);
-      const dv2* const Lb = Lf + NFW;
-      const dv2* const uf0 = Lf + (sw + 1) * 36;
-      const dv2* const ub0 = Lf + sw * 36;
-      const dv2* const ub1 = e1 ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
-      const dv2* const ub2 = e2 ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
-      const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
-      const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;
-      dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;
-      dv2 b3[3][2], f3[3][2], f0[3][2], b0[3][2], lp1[3][2], lp2[3][2];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { b3[c][0] = Cn[co + c * M]; b3[c][1] = Cn[co + c * M + 1]; }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(b3[c][0]), "+v"(b3[c][1]));  // in registers before the DMA replaces them
-      // ---- B: slice x3 + 1 (own sites, halo sites) -> Cn
-      {
-        const char *own, *lft, *rgt;
-        if (INCR_IN && x3 + 1 < L3) {
-          own = ir_own; lft = ir_lft; rgt = ir_rgt;
-          ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
-        } else if (INCR_IN) {
-          own = iw_own; lft = iw_lft; rgt = iw_rgt;
-        } else {
-          int kind, xs, gx3;
-          slice_of(x3 + 1, slot_n, kind, xs, gx3);
-          row_ptrs(kind, xs, gx3, own, lft, rgt);
-        }
-        dma_row(Cn, own, lft, rgt);
-      }
-      BCG_STAMP5(2)   // -x3 read back, row DMAs issued
-      const dv2* const Cown = Cc + wave * CS;
-      const dv2* const Cp1 = Cc + (wave ^ 1) * CS;
-      const dv2* const Cp2 = Cc + (wave ^ 2) * CS;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          f0[c][h] = Cown[co + 3 * M + c * M + h];
-          b0[c][h] = Cown[co - 3 * M + c * M + h];
-        }
-      const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
-      const char* const prow = ip_p;
-      char* const orow = INCR_OUT ? ip_o : reinterpret_cast<char*>(out) + (static_cast<int64_t>(col) + static_cast<int64_t>(slot) * S3) * RB;
-      (void)crow_site;
-      ip_p += id_row;
-      if (INCR_OUT) ip_o += id_row;
-      dv2 pv[3][2], n1[3][2], n2[3][2];
-      double2 acc[3][2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = make_double2(0, 0);
-      const int x0 = x0b + sw;
-      const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
-      dv2 LU[3][6];  // links: LU[k] holds unit (mu, k) -- three entries of U_mu(x), three of U_mu(x - mu) -- two units ahead
-#define BCG5_LD(K, UF, UB)                                                                                   \
-  {                                                                                                          \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
-      LU[K][r] = (UF)[(K) * 3 + r];                                                                          \
-      LU[K][3 + r] = (UB)[r * 3 + (K)];                                                                      \
-    }                                                                                                        \
-  }
-#define BCG5_FM(K, F, B)                                                                                     \
-  {                                                                                                          \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
-      const dv2 u = LU[K][r], v = LU[K][3 + r];                                                              \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                        \
-        t[r][h].x = fma(u.x, F[K][h].x, t[r][h].x); t[r][h].x = fma(-u.y, F[K][h].y, t[r][h].x);             \
-        t[r][h].y = fma(u.x, F[K][h].y, t[r][h].y); t[r][h].y = fma(u.y, F[K][h].x, t[r][h].y);              \
-        t[r][h].x = fma(-v.x, B[K][h].x, t[r][h].x); t[r][h].x = fma(-v.y, B[K][h].y, t[r][h].x);            \
-        t[r][h].y = fma(-v.x, B[K][h].y, t[r][h].y); t[r][h].y = fma(v.y, B[K][h].x, t[r][h].y);             \
-      }                                                                                                      \
-    }                                                                                                        \
-  }
-#define BCG5_DIR(MU, F, B, UFC, UBC, UFN, UBN, LAST, EXTRA)                                                  \
-  {                                                                                                          \
-    const int par = (MU) == 0 ? 0 : ((MU) == 1 ? par1 : ((MU) == 2 ? par2 : par3));                         \
-    const double eta = (par & 1) ? -1.0 : 1.0;                                                               \
-    double2 t[3][2];                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) t[r][0] = t[r][1] = make_double2(0, 0);                    \
-    BCG5_LD(2, UFC, UBC)                                                                                     \
-    BCG5_FM(0, F, B)                                                                                         \
-    if (!(LAST)) BCG5_LD(0, UFN, UBN)                                                                        \
-    BCG5_FM(1, F, B)                                                                                         \
-    if (!(LAST)) BCG5_LD(1, UFN, UBN)                                                                        \
-    EXTRA                                                                                                    \
-    BCG5_FM(2, F, B)                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                            \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                        \
-        acc[r][h].x = fma(eta, t[r][h].x, acc[r][h].x);                                                      \
-        acc[r][h].y = fma(eta, t[r][h].y, acc[r][h].y);                                                      \
-      }                                                                                                      \
-  }
-#define BCG5_LP(LP, CP) { _Pragma("unroll") for (int c = 0; c < 3; ++c) { LP[c][0] = (CP)[co + c * M]; LP[c][1] = (CP)[co + c * M + 1]; } }
-#define BCG5_PIN(text)                                                                                          \
-  asm volatile("; " text : "+v"(acc[0][0].x), "+v"(acc[0][0].y), "+v"(acc[0][1].x), "+v"(acc[0][1].y), "+v"(acc[1][0].x), \
-               "+v"(acc[1][0].y), "+v"(acc[1][1].x), "+v"(acc[1][1].y), "+v"(acc[2][0].x), "+v"(acc[2][0].y), "+v"(acc[2][1].x), "+v"(acc[2][1].y))
-      BCG5_LD(0, uf0, ub0)
-      BCG5_LD(1, uf0, ub0)
-      __builtin_amdgcn_sched_barrier(0);
-      BCG5_DIR(0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG5_LP(lp1, Cp1))
-      BCG5_PIN("direction 0");
-      __builtin_amdgcn_sched_barrier(0);
-      BCG_STAMP5(3)   // direction 0
-      // ---- E: p;  C: links of slice x3 + 1 -> the other image
-      if (MODE != HOP_PLAIN) {
-        asm volatile("; ASYNC_ISSUE p");
-        pv[0][0] = ld_sv_async_a<0>(prow, voff);
-        pv[0][1] = ld_sv_async_a<16>(prow, voff);
-        pv[1][0] = ld_sv_async_a<M * 16>(prow, voff);
-        pv[1][1] = ld_sv_async_a<M * 16 + 16>(prow, voff);
-        pv[2][0] = ld_sv_async_a<2 * M * 16>(prow, voff);
-        pv[2][1] = ld_sv_async_a<2 * M * 16 + 16>(prow, voff);
-        asm volatile("; ASYNC_ISSUED p");
-      }
-      if (more) {
-        dma_links(x3 + 1, ik_f, ik_l, ik_1, ik_2, false);
-        ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      BCG_STAMP5(4)   // p loads and link DMAs issued
-      if (e1) { BCG5_DIR(1, q1v, lp1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG5_LP(lp2, Cp2)) BCG5_PIN("direction 1, forward row outside the bundle"); }
-      else { BCG5_DIR(1, lp1, q1v, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG5_LP(lp2, Cp2)) BCG5_PIN("direction 1, backward row outside the bundle"); }
-      __builtin_amdgcn_sched_barrier(0);
-      BCG_STAMP5(5)   // direction 1
-      // ---- D: the rows that leave the bundle, for the next step
-      if (more) {
-        const char* const a1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
-        const char* const a2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
-        if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
-        asm volatile("; ASYNC_ISSUE n");
-        n1[0][0] = ld_sv_async_a<0>(a1, voff);
-        n1[0][1] = ld_sv_async_a<16>(a1, voff);
-        n1[1][0] = ld_sv_async_a<M * 16>(a1, voff);
-        n1[1][1] = ld_sv_async_a<M * 16 + 16>(a1, voff);
-        n1[2][0] = ld_sv_async_a<2 * M * 16>(a1, voff);
-        n1[2][1] = ld_sv_async_a<2 * M * 16 + 16>(a1, voff);
-        n2[0][0] = ld_sv_async_a<0>(a2, voff);
-        n2[0][1] = ld_sv_async_a<16>(a2, voff);
-        n2[1][0] = ld_sv_async_a<M * 16>(a2, voff);
-        n2[1][1] = ld_sv_async_a<M * 16 + 16>(a2, voff);
-        n2[2][0] = ld_sv_async_a<2 * M * 16>(a2, voff);
-        n2[2][1] = ld_sv_async_a<2 * M * 16 + 16>(a2, voff);
-        asm volatile("; ASYNC_ISSUED n");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      BCG_STAMP5(6)   // next rows issued
-      if (e2) { BCG5_DIR(2, q2v, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG5_PIN("direction 2, forward row outside the bundle"); }
-      else { BCG5_DIR(2, lp2, q2v, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG5_PIN("direction 2, backward row outside the bundle"); }
-      __builtin_amdgcn_sched_barrier(0);
-      BCG_STAMP5(7)   // direction 2
-      // ---- the +x3 row has landed in Cn once at most E, C and D are outstanding
-      wait_vmcnt(nE + (more ? nC + nD : 0));
-      BCG_STAMP5(8)   // wait for the +x3 row
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { f3[c][0] = Cn[co + c * M]; f3[c][1] = Cn[co + c * M + 1]; }
-      BCG5_DIR(3, f3, b3, uf0 + 27, ub3, uf0, ub0, true, )
-      BCG5_PIN("direction 3");
-      __builtin_amdgcn_sched_barrier(0);
-#undef BCG5_LD
-#undef BCG5_FM
-#undef BCG5_DIR
-#undef BCG5_LP
-#undef BCG5_PIN
-      BCG_STAMP5(9)   // direction 3
-      if (more) park_u3(x3 + 1);
-      double2 pw[3][2];
-      if (MODE != HOP_PLAIN) {
-        wait_vmcnt(more ? nC + nD : 0);  // p
-        // the accumulation registers are released to hipcc behind the wait; it moves them where it needs them
-        asm volatile("; ASYNC_RETIRE p" : "+a"(pv[0][0]), "+a"(pv[0][1]), "+a"(pv[1][0]), "+a"(pv[1][1]), "+a"(pv[2][0]), "+a"(pv[2][1]));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          pw[c][0] = make_double2(pv[c][0].x, pv[c][0].y);
-          pw[c][1] = make_double2(pv[c][1].x, pv[c][1].y);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double2 tv;
-          if (MODE == HOP_PLAIN) tv = make_double2(0.5 * acc[r][h].x, 0.5 * acc[r][h].y);
-          else tv = make_double2(fma(c0, pw[r][h].x, -0.5 * acc[r][h].x), fma(c0, pw[r][h].y, -0.5 * acc[r][h].y));
-          st_nt(reinterpret_cast<double2*>(orow + voff + r * M * 16 + h * 16), tv);
-        }
-      BCG_STAMP5(10)  // U_3 carried, wait for p, output, stores
-      // everything but the stores: the links and the next rows have landed before this wave reaches the barrier
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        asm volatile("s_waitcnt vmcnt(%12) ; ASYNC_RETIRE n"
-                     : "+a"(n1[0][0]), "+a"(n1[0][1]), "+a"(n1[1][0]), "+a"(n1[1][1]), "+a"(n1[2][0]), "+a"(n1[2][1]),
-                       "+a"(n2[0][0]), "+a"(n2[0][1]), "+a"(n2[1][0]), "+a"(n2[1][1]), "+a"(n2[2][0]), "+a"(n2[2][1])
-                     : "n"(nS)
-                     : "memory");
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) { q1v[c][hh] = n1[c][hh]; q2v[c][hh] = n2[c][hh]; }
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(nS) : "memory");
-      }
-      if (hw.sync != nullptr && tid == 0 && step_n < hw.sync_stride)
-        __hip_atomic_fetch_add(hw.sync + cls * hw.sync_stride + step_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      seen2 = seen1;
-      seen2_idx = seen1_idx;
-      if (hw.sync != nullptr && tid == 0 && pace && step_n + 2 >= hw.sync_window) {
-        seen1_idx = step_n + 2 - hw.sync_window;
-        seen1 = read_counter(hw.sync + cls * hw.sync_stride + seen1_idx, zero_rt);
-      }
-      if (RING) slot = slot_n;
-      BCG_STAMP5(11)  // end-of-step wait (links, next rows), pacing counters
-    }
-  }
-#ifdef BCG_HOP4B_STAMPS
-  if (lane == 0) {
-    double* o = reinterpret_cast<double*>(partials) + (static_cast<int64_t>(blockIdx.x) * 4 + wave) * 16;
-    for (int i = 0; i < 16; ++i) o[i] = static_cast<double>(seg[i]);
-  }
-#endif
-#undef BCG_STAMP5
-}
-
-template <int MODE, bool RING>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_hop5(
-    LatticeDev lat, const double2* __restrict__ U, const double2* __restrict__ Ughost, const double2* __restrict__ in,
-    const double2* __restrict__ ghost, double2* __restrict__ out, const double2* __restrict__ p, double c0,
-    double2* __restrict__ partials, HopWalk hw, HopWindow win) {
-  hop5_body<MODE, RING>(lat, U, Ughost, in, ghost, out, p, c0, partials, hw, win);
-}
-
 #ifdef BCG_PROBE  // tuning aid: compile only the probed stencil instantiations (seconds instead of minutes)
 template __global__ void k_hop4b<16, HOP_PLAIN, false, false>(LatticeDev, const double2*, const double2*, const double2*,
                                                                const double2*, double2*, const double2*, double, double2*,
@@ -3365,8 +2840,6 @@ template __global__ void k_hop4b<16, HOP_PLAIN, false, false>(LatticeDev, const 
 template __global__ void k_hop4b<16, HOP_SHIFTED, true, false>(LatticeDev, const double2*, const double2*, const double2*,
                                                                 const double2*, double2*, const double2*, double, double2*,
                                                                 HopWalk, HopWindow);
-template __global__ void k_hop5<HOP_PLAIN, false>(LatticeDev, const double2*, const double2*, const double2*, const double2*,
-                                                   double2*, const double2*, double, double2*, HopWalk, HopWindow);
 template __global__ void k_hop4c<16, HOP_PLAIN, false, 0, false>(LatticeDev, const double2*, const double2*, const double2*,
                                                                   const double2*, double2*, const double2*, double, double2*,
                                                                   HopWalk, HopWindow);
@@ -3684,13 +3157,6 @@ static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const
          (pl.hw.p0 / spw) * (pl.hw.p1 / 2) * (pl.hw.p2 / 2) == pl.grid / 8;
 }
 
-// k_hop5 (8 x 2 x 2 tiles, two right-hand sides per lane; m = 16 without the fused Gram product) serves what the bundle
-// sweep serves when the patches are made of whole 8-site tiles
-static bool hop5_ok(const LatticeDev& lat, const HopTuning& tune, const HopPlan& pl, int cls, bool gram, HopMode mode) {
-  return tune.hop5 && !gram && (mode == HOP_PLAIN || mode == HOP_SHIFTED) && pl.win.cb == 0 &&
-         bundle_ok(16, lat, tune, pl, cls, mode == HOP_PLAIN) && pl.hw.p0 % 8 == 0 && pl.grid % 16 == 0;
-}
-
 // The bundle sweep is paced only where it is free: whole-field launches of at least 256 steps per block.  Measured
 // (profiles/r03_pacing_ab_other_shapes.txt): at 64^4 (2048 steps) paced = unpaced in time with 20 % less fabric traffic; at
 // 32^4, m = 8 (64 steps) the paced plain hop takes 0.376 vs 0.360 ms; capacity-mode windows (15-30 slices) 22.3 vs 21.6 ms.
@@ -3740,25 +3206,6 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
     else BCG_LAUNCH4B_CB(MC, HOP_SHIFTED, false);
 #undef BCG_LAUNCH4B_CB
     return grid;
-  }
-  // k_hop5: the bundle sweep with two right-hand sides per lane (m = 16, forms without the fused Gram product)
-  if (M == 16 && hop5_ok(lat, tune, pl, cls, gram, mode)) {
-    HopWalk hwb = hw;
-    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(ntiles, grid, win)))
-      hwb.sync_window = tune.sync.bundle_window < 0 ? -tune.sync.bundle_window : tune.sync.bundle_window;
-    else hwb.sync = nullptr;
-    if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
-    const int grid5 = grid / 2;  // tiles of 8 x 2 x 2 sites: one block per CU
-    const size_t lds5 = sizeof(double2) * (2 * 4 * ((8 + 2) * 3 * 16) + 2 * 4 * ((8 + 1) * 36 + 3 * 8 * 9));
-#define BCG_LAUNCH5(MD, RG)                                                                                          \
-  do {                                                                                                              \
-    allow_lds(k_hop5<MD, RG>, lds5);                                                                                \
-    hipLaunchKernelGGL((k_hop5<MD, RG>), dim3(grid5), dim3(256), lds5, s, lat, U, Ughost, in, ghost, out, p, c0, partials, hwb, win); \
-  } while (0)
-    if (mode == HOP_PLAIN) { if (win.ring > 0) BCG_LAUNCH5(HOP_PLAIN, true); else BCG_LAUNCH5(HOP_PLAIN, false); }
-    else { if (win.ring > 0) BCG_LAUNCH5(HOP_SHIFTED, true); else BCG_LAUNCH5(HOP_SHIFTED, false); }
-#undef BCG_LAUNCH5
-    return grid5;
   }
   // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
   if (bundle_ok(M, lat, tune, pl, cls, mode == HOP_PLAIN)) {
@@ -3867,13 +3314,6 @@ bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuni
   if (!hop_can_split_tiles(m, lat)) return false;
   const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
   return bundle_ok(m, lat, tune, plan_hop4(m, lat, mb, tune, tile_class, win), tile_class, plain);
-}
-
-bool hop_uses_hop5(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
-                   bool gram, HopMode mode) {
-  if (m != 16 || !hop_can_split_tiles(m, lat)) return false;
-  const int mb = tune.blocks > 0 ? tune.blocks : max_blocks;
-  return hop5_ok(lat, tune, plan_hop4(m, lat, mb, tune, tile_class, win), tile_class, gram, mode);
 }
 
 int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* U, const double2* Ughost,

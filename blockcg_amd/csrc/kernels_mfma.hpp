@@ -65,7 +65,6 @@ struct HopTuning {
   int boundary_n = 0;
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
   GramFold fold;                 // set per launch by the context: fold the fused Gram partials in the kernel (column forms)
-  bool hop5 = true;              // m = 16 without the fused Gram product: k_hop5 (two right-hand sides per lane; BCG_HOP5=0: k_hop4b)
   int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
                                  // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
                                  // so CUs are not vacated for the transport; its kernels co-reside where registers allow
@@ -97,8 +96,5 @@ bool hop_folds_gram(int m, const LatticeDev& lat, int max_blocks, const HopTunin
 // true when form 2 is served by k_hop4b (2 x 2 column bundles) rather than k_hop4c
 bool hop_uses_bundle(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
                      bool plain = false);
-// true when that launch is served by k_hop5 (8 x 2 x 2 tiles, two right-hand sides per lane) instead
-bool hop_uses_hop5(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win,
-                   bool gram, HopMode mode);
 
 }  // namespace bcg

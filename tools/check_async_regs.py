@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Build-time check for the hand-waited global loads of k_hop4b's PIPE schedule and of k_hop5 (ld_sv_async).
+"""Build-time check for k_hop4b's hand-waited global loads (ld_sv_async in the PIPE schedule).
 
 hipcc does not see these loads (inline asm): it believes their destination registers hold the values from the moment of
 issue.  Correctness therefore needs that between a group's ISSUE and the hand-written wait that RETIRES it no instruction
 on the path reads, copies or overwrites those registers.  The kernel brackets every group with asm comments
     ; ASYNC_ISSUE <tag>  ...loads...  ; ASYNC_ISSUED <tag>      and marks the point behind the retiring wait     ; ASYNC_RETIRE <tag>
-and this script walks the device assembly of every k_hop4b / k_hop5 instantiation from ISSUED along the control flow (unconditional
+and this script walks the device assembly of every k_hop4b instantiation from ISSUED along the control flow (unconditional
 branches are followed, conditional ones fork) to the RETIRE marker or to a hand-written end-of-step wait (vmcnt(3) or
 less): no instruction on any such path may name a destination register of the group, and every path must end in one.
 

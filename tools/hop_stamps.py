@@ -23,19 +23,19 @@ y = bc.block_fermion_field(ctx, m)
 for _ in range(3):
     D.D(y, B)
 ctx.synchronize()
-nblk = 256 if len(sys.argv) > 1 and sys.argv[1] == "hop5" else 512
-NSEG = 16 if len(sys.argv) > 1 and sys.argv[1] in ("4b", "pipe", "hop5") else 8
+nblk = 512
+NSEG = 16 if len(sys.argv) > 1 and sys.argv[1] in ("4b", "pipe") else 8
 buf = np.zeros(nblk * 4 * NSEG, dtype=np.float64)
 lib = ctx.lib
 lib.bcg_debug_read_scratch.restype = ctypes.c_int
 lib.bcg_debug_read_scratch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 assert lib.bcg_debug_read_scratch(ctx.h, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) == 0
 seg = buf.reshape(nblk, 4, NSEG)
-tiles = 64 ** 4 // (32 if nblk == 256 else 16) // nblk
+tiles = 64 ** 4 // 16 // nblk
 names = ["park+pace", "barrier", "issue(links,dir0)", "dir0", "dir1", "dir2", "dir3(+x3)", "tail(p,store)"]
 if len(sys.argv) > 1 and sys.argv[1] == "4b":
     names = ["pace(thread 0)", "barrier", "issue(DMAs,loads)", "dir0 (LDS only)", "dir1 (+wait loads)", "dir2", "dir3", "tail(park,store)"]
-if len(sys.argv) > 1 and sys.argv[1] in ("pipe", "hop5"):  # the software-pipelined step (PIPE in hop4b_body)
+if len(sys.argv) > 1 and sys.argv[1] == "pipe":  # the software-pipelined step (PIPE in hop4b_body)
     names = ["loop overhead", "barrier", "-x3 readback + row DMAs", "dir0", "issue p + link DMAs", "dir1", "issue next rows", "dir2",
              "WAIT +x3 row", "dir3", "carry U3, WAIT p, output, stores", "WAIT links + next rows"]
 tot = seg.sum(axis=2)
