@@ -3161,8 +3161,12 @@ static bool bundle_ok(int m, const LatticeDev& lat, const HopTuning& tune, const
 // (profiles/r03_pacing_ab_other_shapes.txt): at 64^4 (2048 steps) paced = unpaced in time with 20 % less fabric traffic; at
 // 32^4, m = 8 (64 steps) the paced plain hop takes 0.376 vs 0.360 ms; capacity-mode windows (15-30 slices) 22.3 vs 21.6 ms.
 // BCG_HOP_BUNDLE_SYNC < 0 forces pacing with window |value| everywhere (tests).
-static bool bundle_paced(int ntiles, int grid, const HopWindow& win) {
-  return win.ring == 0 && grid > 0 && ntiles / grid >= 256;
+// Round 4: with the software-pipelined step (m = 16, 32) the capacity-mode windows gain from pacing too -- 64^3 x 128 share, ring
+// 32: hop_ring 18.2 vs 18.8 ms, with the Gram product 23.8 vs 24.4, 107.6-108.1 vs 108.8 ms per iteration
+// (profiles/r04_cap128_pacing_ab.txt) -- so there only the step count decides.
+static bool bundle_paced(int m, int ntiles, int grid, const HopWindow& win) {
+  const bool pipelined = BCG_HOP4B_PIPE != 0 && hop4b_share_images(m) && win.cb == 0;
+  return (win.ring == 0 || pipelined) && grid > 0 && ntiles / grid >= 256;
 }
 
 template <int M>
@@ -3188,7 +3192,7 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
       return -1;
     constexpr int MC = hop4b_share_images(M) ? M : 16;  // (never launched for the other widths)
     HopWalk hwb = hw;
-    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(ntiles, grid, win)))
+    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(M, ntiles, grid, win)))
       hwb.sync_window = tune.sync.bundle_window < 0 ? -tune.sync.bundle_window : tune.sync.bundle_window;
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
@@ -3210,7 +3214,7 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   // k_hop4b: the column sweep over 2 x 2 bundles (whole launches only: the tile classes stay with k_hop4c)
   if (bundle_ok(M, lat, tune, pl, cls, mode == HOP_PLAIN)) {
     HopWalk hwb = hw;  // pacing of the bundle sweep: its own window, long whole-field sweeps only (bundle_paced)
-    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(ntiles, grid, win)))
+    if (tune.sync.bundle_window != 0 && hw.sync && (tune.sync.bundle_window < 0 || bundle_paced(M, ntiles, grid, win)))
       hwb.sync_window = tune.sync.bundle_window < 0 ? -tune.sync.bundle_window : tune.sync.bundle_window;
     else hwb.sync = nullptr;
     if (hwb.sync) (void)hipMemsetAsync(hwb.sync, 0, sizeof(unsigned) * 8 * hwb.sync_stride, s);
