@@ -420,6 +420,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, bytes_in_use = float(t[0].item()), int(t[1].item())
     residual = st.residual
+    n_comms = comm.communicators if transport == "rccl" else None  # 2: the split exchange has a communicator of its own
     st.end()
     if comm is not None and comm.error is not None:
         raise comm.error
@@ -446,7 +447,8 @@ def main():
                                       if args.config == 4 else "")
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
                                       "(64^3x128 per GPU, capacity ring 32)" if default_shape else ""),
-                       "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport},
+                       "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport,
+                       "rccl_communicators": n_comms},
             "iterations_per_sec": its,
             # bytes_alg of SURVEY.md section 8d, V[(14 + 4(S-1)) 48 m + 2 g]: the metric's definition.  The iteration itself
             # moves one field pass less since round 3 (Q rho^-1 is not stored): see bytes_moved_minimum

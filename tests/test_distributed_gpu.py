@@ -219,6 +219,7 @@ def test_bare_bench_command_starts_its_own_ranks(gpus):
     grid = {2: [1, 1, 2, 1], 4: [1, 2, 2, 1]}[gpus]
     assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     assert d["config"]["transport"] == "rccl" and d["capacity_ring_slices"] == 4 and d["config"]["process_grid"] == grid
+    assert d["config"]["rccl_communicators"] == 2  # the split exchange runs on a communicator of its own
     assert d["config"]["global_dims"] == [32 * grid[0], 8 * grid[1], 8 * grid[2], 8]
     comm = d["comm_ms_per_iteration"]
     assert comm and comm["allreduce"] > 0 and comm["pack_faces"] > 0 and any(k.startswith("halo_exchange") for k in comm)
