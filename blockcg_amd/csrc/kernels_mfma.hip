@@ -1848,7 +1848,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   constexpr int RBK = (SPW * 9 + 63) / 64;
   constexpr bool SHARE = hop4b_share_images(M);   // two link images per wave (LDS-DMA into the one not being read)
   constexpr bool PARTNER = SHARE && !CB;           // in-bundle backward links from the partner waves, U_3(x - 3) carried
-  constexpr bool PIPE = BCG_HOP4B_PIPE != 0 && hop4b_share_images(M) && !CB && !RESID;  // the software-pipelined step (below)
+  constexpr bool PIPE = BCG_HOP4B_PIPE != 0 && hop4b_share_images(M) && !RESID;  // the software-pipelined step (below; the checkerboard form too)
   constexpr int HB = 3 * M * 16;                  // bytes of one site = of one halo site
   constexpr int NHD = (HB + 1023) / 1024;         // DMA instructions per halo site
   constexpr int RB = 3 * M * 16;           // bytes of one site of a field
@@ -2315,7 +2315,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       }
       constexpr int nB = 3 + 2 * NHD;                               // row DMAs
       constexpr int nE = MODE == HOP_PLAIN ? 0 : 3;                 // p
-      const int nC = RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);     // link DMAs of this wave
+      // link DMAs of this wave (checkerboard form: the forward links and all four directions' backward links, every wave)
+      const int nC = CB ? RFW + 4 * RBK : RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);
       constexpr int nD = 6, nS = 3;
       (void)nB;
       for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
@@ -2345,8 +2346,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         BCG_STAMPB(1)   // barrier
         const dv2* const Lf = image(x3, wave);
         const dv2* const Lb = Lf + NFW;
-        const dv2* const ub1 = e1 ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
-        const dv2* const ub2 = e2 ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
+        const dv2* const ub1 = (PARTNER && e1) ? image(x3, wave ^ 1) + (sw + 1) * 36 + 9 : Lb + sw * 9;
+        const dv2* const ub2 = (PARTNER && e2) ? image(x3, wave ^ 2) + (sw + 1) * 36 + 18 : Lb + (SPW + sw) * 9;
+        const int rr = CB ? (x1 + x2 + x3 + win.cb_parity) & 1 : 0;  // CB: this row's x0 = 2 k + rr
         const dv2* const Cc = Cbase + (x3 & 1) * NW * CS;
         dv2* const Cn = Cbase + (((x3 + 1) & 1) * NW + wave) * CS;
         dv2 f0[3], b0[3], b3[3], f3[3], lp1[3], lp2[3];
@@ -2389,8 +2391,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         const dv2* const Cp2 = Cc + (wave ^ 2) * CS;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          f0[c] = Cown[co + 3 * M + c * M];
-          b0[c] = Cown[co - 3 * M + c * M];
+          f0[c] = Cown[co + (CB ? rr : 1) * 3 * M + c * M];      // CB: input sites k + rr and k - 1 + rr
+          b0[c] = Cown[co + (CB ? rr - 1 : -1) * 3 * M + c * M];
         }
         const int64_t crow_site = static_cast<int64_t>(col) + static_cast<int64_t>(x3) * S3;
         const char* const prow = INCR ? ip_p : reinterpret_cast<const char*>(p) + crow_site * RB;
@@ -2399,7 +2401,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         if (INCR_OUT) ip_o += id_row;
         dv2 pv[3], n1[3], n2[3];
         double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-        const int x0 = x0b + sw;
+        const int x0 = CB ? 2 * (x0b + sw) + rr : x0b + sw;
         const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
 // The links are read from the images three entries of U_mu(x) and three of U_mu(x - mu) at a time -- the six a "unit" (mu, k) of
 // 24 FMAs needs -- one unit AHEAD of their use (two register slots, LU[(3 mu + k) & 1]), written out in that order in the
@@ -2459,7 +2461,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         constexpr bool LNKAHEAD = MODE == HOP_PLAIN;
         dv2 LU[2][6];
         const dv2* const uf0 = Lf + (sw + 1) * 36;          // U_mu(x): + 9 mu
-        const dv2* const ub0 = Lf + sw * 36;                // U_0(x - 0): the left neighbour's forward link
+        const dv2* const ub0 = CB ? Lb + (3 * SPW + sw) * 9 : Lf + sw * 36;  // U_0(x - 0): the left neighbour's forward link (CB: gathered)
         const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
         if (LNKAHEAD) BCG_LD(0, 0, uf0, ub0)
         __builtin_amdgcn_sched_barrier(0);
@@ -2476,7 +2478,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           asm volatile("; ASYNC_ISSUED p");
         }
         if (more) {
-          if (INCR) {
+          if (CB) {
+            dma_links_cb(x3 + 1);
+          } else if (INCR) {
             dma_links_at_s(x3 + 1, ik_f, ik_l, ik_1, ik_2);
             ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;
           } else {
@@ -2526,7 +2530,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #undef BCG_PIPE_PIN
 #undef BCG_PIPE_APART
         BCG_STAMPB(9)   // direction 3
-        if (more) park_u3(x3 + 1);  // U_3(x - 3) of the next slice = U_3 of this one (ds_read / ds_write; the DMAs fill the rest)
+        if (more && !CB) park_u3(x3 + 1);  // U_3(x - 3) of the next slice = U_3 of this one (ds_read / ds_write; the DMAs fill the rest)
         double2 tv[3], pw[3];
         if (MODE != HOP_PLAIN) {
           wait_vmcnt(more ? nC + nD : 0);  // p
