@@ -1217,6 +1217,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)
   if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_CHUNK")) c->ring_chunk_override = std::atoi(e);
+  if (const char* e = std::getenv("BCG_DEBUG_FIELD_BUDGET")) c->debug_field_budget = static_cast<size_t>(std::atoll(e));
   if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
@@ -1412,6 +1413,7 @@ int bcg_capacity_mode(bcg_context* c, int ring_slices) {
     if (ring_slices != 0) {
       for (auto& kv : c->tmp_field) {
         (void)hipFree(kv.second->base);
+        c->field_bytes_live -= field_bytes(kv.second);
         delete kv.second;
       }
       c->tmp_field.clear();
@@ -1491,7 +1493,9 @@ int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
   // streaming kernels read the same offset of up to nine of them at once with identical low address bits.  A per-field
   // stagger (a multiple of 256 B, so alignment is kept) spreads those accesses over the memory channels.
   const size_t lead = c->field_stagger * static_cast<size_t>(c->fields_created % 16);
-  hipError_t e = hipMalloc(&f->base, field_bytes(f) + c->field_stagger * 16);
+  hipError_t e = (c->debug_field_budget && c->field_bytes_live + field_bytes(f) > c->debug_field_budget)
+                     ? hipErrorOutOfMemory  // test aid: a deterministic stand-in for a full device (tests/test_robustness.py)
+                     : hipMalloc(&f->base, field_bytes(f) + c->field_stagger * 16);
   if (e != hipSuccess) {
     delete f;
     c->err = std::string("bcg_field_create: hipMalloc: ") + hipGetErrorString(e);
@@ -1499,6 +1503,7 @@ int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
   }
   f->d = reinterpret_cast<double2*>(static_cast<char*>(f->base) + lead);
   c->fields_created += 1;
+  c->field_bytes_live += field_bytes(f);
   *out = f;
   return BCG_OK;
 }
@@ -1530,6 +1535,7 @@ int bcg_field_destroy(bcg_field* f) {
   if (!f) return BCG_OK;
   (void)hipStreamSynchronize(f->ctx->stream);
   (void)hipFree(f->base);
+  f->ctx->field_bytes_live -= field_bytes(f);
   delete f;
   return BCG_OK;
 }

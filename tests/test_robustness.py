@@ -114,50 +114,56 @@ def test_error_inside_a_group_leaves_every_shift_current(bc, m, dims, depth, mon
 
 def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypatch):
     """bcg_sbcgrq_begin allocates what the operator needs (tmp, scratch) BEFORE the optional residual buffers of the grouped
-    shift updates.  With free memory = base plan + 1.5 fields the default depth 4 (two extra fields) must fall back to
-    depth 3 and run; round 3 took the one extra field that fitted and then failed on tmp in the first iteration."""
-    import torch
+    shift updates.  With room for the base plan + 1.5 fields the default depth 4 (two extra fields) must fall back to depth 3
+    and run; round 3 took the one extra field that fitted and then failed on tmp in the first iteration.
+    The "full device" is BCG_DEBUG_FIELD_BUDGET, the library's deterministic stand-in for an out-of-memory on field
+    allocations (free device memory as the runtime reports it is no measure of what a process can still allocate once
+    earlier tests have allocated and freed hundreds of gigabytes in it)."""
     for k in ("BCG_HOP_BLOCKS", "BCG_HOP_PATCH", "BCG_PAIR_SHIFTS"):
         monkeypatch.delenv(k, raising=False)
     dims, m, shifts, mass, iters = [32, 32, 32, 32], 16, [0.0, 1e-4, 1e-2, 1.0], 0.3, 7
     field = 32 ** 4 * 3 * m * 16
 
-    def run(limit):
+    def run(extra_fields):
+        # the caller's B and X_s (5 fields), then inside begin: P_s (4), T, Q (B is kept), tmp = 7 fields
+        if extra_fields is None:
+            monkeypatch.delenv("BCG_DEBUG_FIELD_BUDGET", raising=False)
+        else:
+            monkeypatch.setenv("BCG_DEBUG_FIELD_BUDGET", str(int((12 + extra_fields) * field)))
         ctx = bc.Context(dims)
         ctx.profiling(True)
         D = bc.dirac_op(ctx, mass, seed=11)
         B = bc.block_fermion_field(ctx, m).setRandom(seed=12)
         X = [bc.block_fermion_field(ctx, m) for _ in shifts]
-        ballast = None
-        if limit:
-            # still to come inside begin / the first iteration: P_s (4), T, Q (B is kept), tmp = 7 fields + scratch (< 100 MB)
-            spare = 7 * field + field * 3 // 2 + (100 << 20)
-            torch.cuda.empty_cache()  # (torch would serve the ballast from blocks it has cached: free memory would not move)
-            ballast = []
-            for _ in range(4):  # until the runtime itself reports `spare` (+ < 64 MB) free
-                free = _free_bytes()
-                assert free >= spare
-                if free - spare < (64 << 20):
-                    break
-                ballast.append(torch.empty(free - spare, dtype=torch.uint8, device="cuda"))
-            assert _free_bytes() - spare < (64 << 20)
         st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
         st.iterate(iters)
         st.end()
         prof = ctx.profile()
         out = [x.download_sites(np.arange(0, ctx.V, 4099, dtype=np.int64)) for x in X]
-        del ballast
+        del X, B, D
         ctx.close()
         gc.collect()
-        torch.cuda.empty_cache()
-        return out, prof
+        return out, {k for k in prof if k.startswith("phaseC")}
 
-    a, pa = run(limit=True)
-    b, pb = run(limit=False)
-    assert "phaseC_multi3" in pa and "phaseC_multi4" not in pa, sorted(k for k in pa if k.startswith("phaseC"))  # depth 3 under the limit
-    assert "phaseC_multi4" in pb                                               # depth 4 with room
+    a, pa = run(1.5)     # one of the two extra buffers fits: groups of three
+    b, pb = run(None)    # no limit: groups of four
+    c, pc = run(0.5)     # none fits: groups of two (T doubles as the second residual buffer)
+    assert pa == {"phaseC", "phaseC_multi3"}, pa            # 7 iterations = 3 + 3 + 1
+    assert pb == {"phaseC", "phaseC_multi4", "phaseC_multi3"}, pb   # 4 + 3
+    assert pc == {"phaseC", "phaseC_multi2"}, pc            # 2 + 2 + 2 + 1
     for s in range(len(shifts)):
-        assert np.array_equal(a[s], b[s])  # the grouping depth never changes the iterates
+        assert np.array_equal(a[s], b[s]) and np.array_equal(c[s], b[s])  # the grouping depth never changes the iterates
+    # and a budget below the base plan is an error at begin, not a crash in the first iteration
+    monkeypatch.setenv("BCG_DEBUG_FIELD_BUDGET", str(int(11.5 * field)))
+    ctx = bc.Context(dims)
+    D = bc.dirac_op(ctx, mass, seed=11)
+    B = bc.block_fermion_field(ctx, m).setRandom(seed=12)
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    with pytest.raises(bc.BlockCGError) as e:
+        bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
+    assert e.value.code == 3 and "out of memory" in str(e.value)  # BCG_ERR_HIP
+    del X, B, D
+    ctx.close()
 
 
 def test_profile_reset_clears_bytes_and_flops(bc):
