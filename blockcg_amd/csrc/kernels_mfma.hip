@@ -71,6 +71,17 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #ifndef BCG_HOP4B_PIPE
 #define BCG_HOP4B_PIPE 1
 #endif
+// SPREAD (bit mask per form): parts of the step's vector-memory instructions issued one or two at a time behind the 24-FMA
+// units instead of in a group behind a direction -- 1: the row DMAs, 2: the link DMAs, 4: the second group of next-step
+// rows behind direction 2 (the waits only need rows first, p second; the rest may come in any order).  Measured at 64^4,
+// three alternating runs per build (profiles/r04_stencil_spread.txt): fused form 11.41 ms grouped, 11.27 with 6, 11.31 with 7,
+// 11.52 with 3; plain form 8.69 grouped, 8.67 with 1 or 4, 8.94 with 2 -- i.e. the queueing of grouped issue is worth 1 %.
+#ifndef BCG_HOP4B_SPREAD
+#define BCG_HOP4B_SPREAD 6
+#endif
+#ifndef BCG_HOP4B_SPREAD_PLAIN
+#define BCG_HOP4B_SPREAD_PLAIN 0
+#endif
 __device__ __forceinline__ void glds16_link(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -2318,6 +2329,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       // link DMAs of this wave (checkerboard form: the forward links and all four directions' backward links, every wave)
       const int nC = CB ? RFW + 4 * RBK : RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);
       constexpr int nD = 6, nS = 3;
+      constexpr int SPREAD = MODE == HOP_PLAIN ? BCG_HOP4B_SPREAD_PLAIN : BCG_HOP4B_SPREAD;  // 1: rows, 2: links, 4: second next-row group
+      constexpr bool SP_B = (SPREAD & 1) != 0, SP_C = (SPREAD & 2) != 0, SP_D = (SPREAD & 4) != 0;
       (void)nB;
       for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
         const bool more = x3 + 1 < x3_end;
@@ -2356,6 +2369,9 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         for (int c = 0; c < 3; ++c) b3[c] = Cn[co + c * M];  // -x3 neighbour: the slot's old contents
         asm volatile("" : "+v"(b3[0]), "+v"(b3[1]), "+v"(b3[2]));  // in registers before the DMA below replaces them
         // ---- B: slice x3 + 1 (own sites, halo sites) -> Cn
+        const char* b_own;
+        const char* b_lft;
+        const char* b_rgt;
         {
           const char* own;
           const char* lft;
@@ -2370,20 +2386,30 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
             slice_of(x3 + 1, slot_n, kind, xs, gx3);
             row_ptrs3(kind, xs, gx3, own, lft, rgt);
           }
-          const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(Cn));
-          glds16_s(own, fo, cn + HB);
-          glds16_s(own, fo + 1024, cn + HB + 1024);
-          glds16_s(own, fo + 2048, cn + HB + 2048);
-          static_assert(NHD <= 2, "halo site: at most two DMA instructions");
-          if (lane * 16 < HB) {
-            glds16_s(lft, fo, cn);
-            glds16_s(rgt, fo, cn + (SPW + 1) * HB);
-          }
-          if (NHD > 1 && lane * 16 + 1024 < HB) {
-            glds16_s(lft, fo + 1024, cn + 1024);
-            glds16_s(rgt, fo + 1024, cn + (SPW + 1) * HB + 1024);
-          }
+          b_own = own; b_lft = lft; b_rgt = rgt;
         }
+        const unsigned cn = __builtin_amdgcn_readfirstlane(lds_addr_of(Cn));
+        static_assert(NHD <= 2, "halo site: at most two DMA instructions");
+        // the row's DMAs in issue order: own sites (3 KB at every width), then the halo sites
+#define BCG_ROW_PIECE(I)                                                                 \
+  {                                                                                      \
+    if ((I) == 0) glds16_s(b_own, fo, cn + HB);                                          \
+    if ((I) == 1) glds16_s(b_own, fo + 1024, cn + HB + 1024);                            \
+    if ((I) == 2) glds16_s(b_own, fo + 2048, cn + HB + 2048);                            \
+    if ((I) == 3) {                                                                      \
+      if (lane * 16 < HB) {                                                              \
+        glds16_s(b_lft, fo, cn);                                                         \
+        glds16_s(b_rgt, fo, cn + (SPW + 1) * HB);                                        \
+      }                                                                                  \
+      if (NHD > 1 && lane * 16 + 1024 < HB) {                                            \
+        glds16_s(b_lft, fo + 1024, cn + 1024);                                           \
+        glds16_s(b_rgt, fo + 1024, cn + (SPW + 1) * HB + 1024);                          \
+      }                                                                                  \
+    }                                                                                    \
+  }
+        BCG_ROW_PIECE(0)
+        BCG_ROW_PIECE(1)
+        if (!SP_B) { BCG_ROW_PIECE(2) BCG_ROW_PIECE(3) }
         BCG_STAMPB(2)   // -x3 read back, row DMAs issued
         // neighbours inside the bundle, from the row slots of this slice
         const dv2* const Cown = Cc + wave * CS;
@@ -2428,22 +2454,27 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   }
 // direction MU (S0: the slot of its unit 0 = MU & 1) with forward neighbour F, backward neighbour B; UFN / UBN: the next
 // direction's link pointers (unused if LAST); EXTRA: LDS reads the next direction needs, issued under this one's last unit
-#define BCG_PIPE_DIR(MU, S0, F, B, UFC, UBC, UFN, UBN, LAST, EXTRA)                                          \
+#define BCG_PIPE_DIR(MU, S0, F, B, UFC, UBC, UFN, UBN, LAST, EXTRA, V0, V1)                                  \
   {                                                                                                          \
     const int par = (MU) == 0 ? 0 : ((MU) == 1 ? par1 : ((MU) == 2 ? par2 : par3));                         \
     const double eta = (par & 1) ? -1.0 : 1.0;                                                               \
     double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
+    /* V0, V1: vector-memory instructions issued behind the first and the second unit (SPREAD), pinned by the barriers */ \
     if (LNKAHEAD) {                                                                                          \
       BCG_LD(1 - (S0), 1, UFC, UBC)                                                                          \
       BCG_FM(S0, 0, F, B)                                                                                    \
+      BCG_PIPE_SLOT(V0)                                                                                      \
       BCG_LD(S0, 2, UFC, UBC)                                                                                \
       BCG_FM(1 - (S0), 1, F, B)                                                                              \
+      BCG_PIPE_SLOT(V1)                                                                                      \
       if (!(LAST)) BCG_LD(1 - (S0), 0, UFN, UBN)                                                             \
       EXTRA                                                                                                  \
       BCG_FM(S0, 2, F, B)                                                                                    \
     } else { /* the form with the fused product has no registers to spare: each unit's links right in front of its FMAs */ \
       BCG_LD(0, 0, UFC, UBC) BCG_FM(0, 0, F, B)                                                              \
+      BCG_PIPE_SLOT(V0)                                                                                      \
       BCG_LD(0, 1, UFC, UBC) BCG_FM(0, 1, F, B)                                                              \
+      BCG_PIPE_SLOT(V1)                                                                                      \
       EXTRA                                                                                                  \
       BCG_LD(0, 2, UFC, UBC) BCG_FM(0, 2, F, B)                                                              \
     }                                                                                                        \
@@ -2451,6 +2482,12 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       acc[r].x = fma(eta, t[r].x, acc[r].x);                                                                 \
       acc[r].y = fma(eta, t[r].y, acc[r].y);                                                                 \
     }                                                                                                        \
+  }
+#define BCG_PIPE_SLOT(V)                     \
+  if (SPREAD) {                              \
+    __builtin_amdgcn_sched_barrier(0);       \
+    V                                        \
+    __builtin_amdgcn_sched_barrier(0);       \
   }
 // the partner waves' rows of this slice (x1 / x2 neighbours inside the bundle): read a direction ahead of their use
 #define BCG_LD_LP(LP, CP) { _Pragma("unroll") for (int c = 0; c < 3; ++c) LP[c] = (CP)[co + c * M]; }
@@ -2465,11 +2502,12 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
         if (LNKAHEAD) BCG_LD(0, 0, uf0, ub0)
         __builtin_amdgcn_sched_barrier(0);
-        BCG_PIPE_DIR(0, 0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG_LD_LP(lp1, Cp1))
+        BCG_PIPE_DIR(0, 0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG_LD_LP(lp1, Cp1), if (SP_B) BCG_ROW_PIECE(2), if (SP_B) BCG_ROW_PIECE(3))
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
+#undef BCG_ROW_PIECE
         BCG_STAMPB(3)   // direction 0
-        // ---- E: p;  C: links of slice x3 + 1 -> the other image
+        // ---- E: p;  C: links of slice x3 + 1 -> the other image (the INCR form in three pieces: forward 1, forward 2, the rest)
         if (MODE != HOP_PLAIN) {
           asm volatile("; ASYNC_ISSUE p");
           pv[0] = ld_sv_async<0>(prow, voff);
@@ -2477,7 +2515,35 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           pv[2] = ld_sv_async<2 * M * 16>(prow, voff);
           asm volatile("; ASYNC_ISSUED p");
         }
-        if (more) {
+        constexpr bool C_PIECES = SP_C && INCR && !CB;  // (closed-form / checkerboard link DMAs stay one group)
+        const unsigned imgn = __builtin_amdgcn_readfirstlane(lds_addr_of(image(x3 + 1, wave)));
+#define BCG_LINK_PIECE(I)                                                                                    \
+  if (more) {                                                                                                \
+    if ((I) == 0) {                                                                                          \
+      if (lane < SPW * 36) glds16_s(ik_f, fo, imgn + 36 * 16);                                               \
+    }                                                                                                        \
+    if ((I) == 1) {                                                                                          \
+      if (RFW > 1 && lane + 64 < SPW * 36) glds16_s(ik_f, fo + 1024, imgn + (36 + 64) * 16);                 \
+    }                                                                                                        \
+    if ((I) == 2) {                                                                                          \
+      if (RFW > 2 && lane + 128 < SPW * 36) glds16_s(ik_f, fo + 2048, imgn + (36 + 128) * 16);               \
+      if (lane < 9) glds16_s(ik_l, fo, imgn);                                                                \
+    }                                                                                                        \
+    if ((I) == 3) {                                                                                          \
+      if (!e1) {                                                                                             \
+        if (lane < SPW * 9) glds16_s(ik_1, BO_SEL(k_b1, 0), imgn + NFW * 16);                                \
+        if (RBK > 1 && lane + 64 < SPW * 9) glds16_s(ik_1, BO_SEL(k_b1, 1), imgn + (NFW + 64) * 16);         \
+      }                                                                                                      \
+      if (!e2) {                                                                                             \
+        if (lane < SPW * 9) glds16_s(ik_2, BO_SEL(k_b2, 0), imgn + (NFW + SPW * 9) * 16);                    \
+        if (RBK > 1 && lane + 64 < SPW * 9) glds16_s(ik_2, BO_SEL(k_b2, 1), imgn + (NFW + SPW * 9 + 64) * 16); \
+      }                                                                                                      \
+      ik_f += id_f; ik_l += id_l; ik_1 += id_1; ik_2 += id_2;                                                \
+    }                                                                                                        \
+  }
+        if (C_PIECES) {
+          // (behind the units of directions 1 and 2)
+        } else if (more) {
           if (CB) {
             dma_links_cb(x3 + 1);
           } else if (INCR) {
@@ -2489,43 +2555,59 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         }
         __builtin_amdgcn_sched_barrier(0);
         BCG_STAMPB(4)   // p loads and link DMAs issued
-        if (e1) { BCG_PIPE_DIR(1, 1, q1, lp1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2)) BCG_PIPE_APART("direction 1, forward row outside the bundle"); }
-        else { BCG_PIPE_DIR(1, 1, lp1, q1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2)) BCG_PIPE_APART("direction 1, backward row outside the bundle"); }
+#define BCG_C1 if (C_PIECES) { BCG_LINK_PIECE(0) }
+#define BCG_C2 if (C_PIECES) { BCG_LINK_PIECE(1) }
+        if (e1) { BCG_PIPE_DIR(1, 1, q1, lp1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(1, 1, lp1, q1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, backward row outside the bundle"); }
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
+#undef BCG_C1
+#undef BCG_C2
         BCG_STAMPB(5)   // direction 1
-        // ---- D: the rows that leave the bundle, for the next step
-        if (more) {
-          const char* const a1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
-          const char* const a2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
-          if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
-          asm volatile("; ASYNC_ISSUE n");
-          n1[0] = ld_sv_async<0>(a1, voff);
-          n1[1] = ld_sv_async<M * 16>(a1, voff);
-          n1[2] = ld_sv_async<2 * M * 16>(a1, voff);
-          n2[0] = ld_sv_async<0>(a2, voff);
-          n2[1] = ld_sv_async<M * 16>(a2, voff);
-          n2[2] = ld_sv_async<2 * M * 16>(a2, voff);
-          asm volatile("; ASYNC_ISSUED n");
-        }
+        // ---- D: the rows that leave the bundle, for the next step (two groups of three loads; with SPREAD the second one
+        // behind direction 2 -- not inside it: the direction's two code paths would each get their own registers for it and
+        // a copy where they join, in front of the wait -- and the rest of the link DMAs behind direction 2's units.  The waits
+        // only need the rows first and p second: E, C and D may come in any order)
+        const char* const a_n1 = INCR_IN ? io_1 : row_o(k_o1, a_o1, s_o1, x3 + 1, slot_n);
+        const char* const a_n2 = INCR_IN ? io_2 : row_o(k_o2, a_o2, s_o2, x3 + 1, slot_n);
+        if (INCR_IN) { io_1 += id_o1; io_2 += id_o2; }
+#define BCG_NEXT_ROW(TAG, N, A)                          \
+  if (more) {                                            \
+    asm volatile("; ASYNC_ISSUE " TAG);                  \
+    N[0] = ld_sv_async<0>(A, voff);                      \
+    N[1] = ld_sv_async<M * 16>(A, voff);                 \
+    N[2] = ld_sv_async<2 * M * 16>(A, voff);             \
+    asm volatile("; ASYNC_ISSUED " TAG);                 \
+  }
+        BCG_NEXT_ROW("n1", n1, a_n1)
+        if (!SP_D) { BCG_NEXT_ROW("n2", n2, a_n2) }
         __builtin_amdgcn_sched_barrier(0);
         BCG_STAMPB(6)   // next rows issued
-        if (e2) { BCG_PIPE_DIR(2, 0, q2, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
-        else { BCG_PIPE_DIR(2, 0, lp2, q2, uf0 + 18, ub2, uf0 + 27, ub3, false, ) BCG_PIPE_APART("direction 2, backward row outside the bundle"); }
+#define BCG_C3 if (C_PIECES) { BCG_LINK_PIECE(2) }
+#define BCG_C4 if (C_PIECES) { BCG_LINK_PIECE(3) }
+        if (e2) { BCG_PIPE_DIR(2, 0, q2, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(2, 0, lp2, q2, uf0 + 18, ub2, uf0 + 27, ub3, false, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, backward row outside the bundle"); }
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
+        if (SP_D) { BCG_NEXT_ROW("n2", n2, a_n2) }
+        __builtin_amdgcn_sched_barrier(0);
+#undef BCG_C3
+#undef BCG_C4
+#undef BCG_LINK_PIECE
+#undef BCG_NEXT_ROW
         BCG_STAMPB(7)   // direction 2
         // ---- the +x3 row has landed in Cn once at most E, C and D (and the touches) are outstanding
         wait_vmcnt(nE + (more ? nC + nD : 0));
         BCG_STAMPB(8)   // wait for the +x3 row
 #pragma unroll
         for (int c = 0; c < 3; ++c) f3[c] = Cn[co + c * M];
-        BCG_PIPE_DIR(3, 1, f3, b3, uf0 + 27, ub3, uf0, ub0, true, )
+        BCG_PIPE_DIR(3, 1, f3, b3, uf0 + 27, ub3, uf0, ub0, true, , , )
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
 #undef BCG_LD
 #undef BCG_FM
 #undef BCG_PIPE_DIR
+#undef BCG_PIPE_SLOT
 #undef BCG_LD_LP
 #undef BCG_PIPE_PIN
 #undef BCG_PIPE_APART
@@ -2559,7 +2641,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         // everything but the stores: the links and the next rows have landed before this wave reaches the barrier
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-          asm volatile("s_waitcnt vmcnt(%24) ; ASYNC_RETIRE n\n\t"
+          asm volatile("s_waitcnt vmcnt(%24) ; ASYNC_RETIRE n1 ASYNC_RETIRE n2\n\t"
                        "v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\tv_mov_b64 %2, %14\n\tv_mov_b64 %3, %15\n\tv_mov_b64 %4, %16\n\tv_mov_b64 %5, %17\n\t"
                        "v_mov_b64 %6, %18\n\tv_mov_b64 %7, %19\n\tv_mov_b64 %8, %20\n\tv_mov_b64 %9, %21\n\tv_mov_b64 %10, %22\n\tv_mov_b64 %11, %23"
                        : "=&v"(q1[0].x), "=&v"(q1[0].y), "=&v"(q1[1].x), "=&v"(q1[1].y), "=&v"(q1[2].x), "=&v"(q1[2].y),
