@@ -412,6 +412,17 @@ int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
   if (!c->distributed) return BCG_OK;
   const size_t site_bytes = static_cast<size_t>(3) * f->m * sizeof(double2);
   BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
+  if (f->parity >= 0) {
+    // a half-volume field: every face holds half its sites (kernels_generic.hip: k_pack_faces_half), at half the offsets
+    // of the full plan -- the same messages with half the bytes per site (face sizes are even: every extent is)
+    {
+      ProfScope ps(c, "pack_faces");
+      bcg::launch_pack_faces_half(c->stream, f->m, c->lat, f->parity, f->d, c->halo_send);
+    }
+    BCG_TRY(check_launch(c, "pack_faces"));
+    ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
+    return exchange_faces(c, site_bytes / 2, split);
+  }
   {
     ProfScope ps(c, "pack_faces");
     bcg::launch_pack_faces(c->stream, f->m, c->lat, f->d, c->halo_send);
@@ -853,7 +864,11 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
 int reserve_operator_scratch(bcg_context* c, const bcg_field* like) {
   const int m = like->m;
   bcg_field* tmp;
-  if (like->parity >= 0) return get_tmp_half(c, m, 1 - like->parity, &tmp);
+  if (like->parity >= 0) {
+    BCG_TRY(get_tmp_half(c, m, 1 - like->parity, &tmp));
+    if (c->distributed) BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * 3 * m * sizeof(double2)));
+    return BCG_OK;
+  }
   if (fast_hop(c, m)) BCG_TRY(ensure_scratch(c));
   if (capacity_path(c, m)) return ensure_ring_scratch(c, m);
   BCG_TRY(get_tmp(c, m, &tmp));
@@ -871,12 +886,21 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     const int m = P->m;
     bcg_field* tmp;
     BCG_TRY(get_tmp_half(c, m, 1 - P->parity, &tmp));
+    BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+    BCG_TRY(halo_field(c, P));  // (a lattice divided over ranks: the half faces of the source, then below those of tmp)
     // the bundle sweep in its checkerboard form (m = 16, compact row a multiple of the tile, patch walk), else the generic kernel
     bcg::LatticeDev latc = c->lat;
     latc.L[0] /= 2;
     latc.V /= 2;
     for (int mu = 1; mu < 4; ++mu) latc.stride[mu] /= 2;
-    const bool fast = fast_hop(c, m) && (m == 16 || m == 32) && c->ndim == 4 && latc.L[0] > 0 && bcg::hop_can_split_tiles(m, latc);
+    for (int mu = 0; mu < 4; ++mu) {  // half ghost faces: half the sites at half the offsets, compact in x0 like the field
+      latc.face_sites[mu] /= 2;
+      latc.ghost_off[mu][0] /= 2;
+      latc.ghost_off[mu][1] /= 2;
+    }
+    // (direction 0 divided over ranks: the compact row's end sites would need the ghost face in one row parity only -- generic kernel)
+    const bool fast = fast_hop(c, m) && (m == 16 || m == 32) && c->ndim == 4 && latc.L[0] > 0 && !c->lat.split[0] &&
+                      bcg::hop_can_split_tiles(m, latc);
     int nb1 = -1, nb2 = -1;
     if (fast) {
       BCG_TRY(ensure_scratch(c));
@@ -890,6 +914,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
       }
       if (nb1 >= 0) {
         BCG_TRY(check_launch(c, "hop_half"));
+        BCG_TRY(halo_field(c, tmp));
         const bool gram = gram_blocks != nullptr && m == 16;  // the fused product exists at m = 16 (as in the full-volume sweep)
         bcg::HopTuning tune = c->hop_tune;
         const bool fold = gram && gram_folded;
@@ -912,12 +937,14 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     }
     {
       ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2));
-      bcg::launch_hop_half(c->stream, m, c->lat, tmp->parity, g->U, P->d, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
+      bcg::launch_hop_half(c->stream, m, c->lat, tmp->parity, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
     }
     BCG_TRY(check_launch(c, "hop_half"));
+    BCG_TRY(halo_field(c, tmp));
     {
       ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2));
-      bcg::launch_hop_half(c->stream, m, c->lat, T->parity, g->U, tmp->d, T->d, bcg::HOP_SHIFTED, P->d, mass * mass + sigma0);
+      bcg::launch_hop_half(c->stream, m, c->lat, T->parity, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
+                           mass * mass + sigma0);
     }
     return check_launch(c, "hop_half_shifted");
   }
@@ -1468,11 +1495,12 @@ int bcg_sbcgrq_device_bytes(const bcg_context* c, int m, int n_shifts, int consu
 int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int consume_B, size_t* bytes_out) {
   DeviceScope on_device(c);
   if (!c || !bytes_out || n_shifts < 1 || !bcg::width_supported(m)) return BCG_ERR_INVALID;
-  if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
   const size_t half = static_cast<size_t>(c->lat.V / 2) * 3 * m * sizeof(double2);
   size_t total = half * (2 * static_cast<size_t>(n_shifts) + 2 + (consume_B ? 0 : 1) + 1);  // X_s, P_s, Q, T (+ B), tmp
   total += half * std::max(0, pair_shifts_depth(c, m, n_shifts) - 2);                       // further residual buffers
   total += static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);                  // links
+  if (c->distributed)  // send + receive faces (allocated at the full-field size: the same buffers serve full fields), ghost links
+    total += static_cast<size_t>(c->ghost_sites) * (2 * 3 * m + 9) * sizeof(double2);
   total += static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2) + kMatSlotBytes * (kMatSlots + 1);
   *bytes_out = total;
   return BCG_OK;
@@ -1484,7 +1512,7 @@ namespace {
 int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
   if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
   if (parity >= 0) {
-    if (c->distributed) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: the lattice must not be divided over ranks");
+    if (c->distributed && c->ndim < 2) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields on a lattice divided over ranks: two dimensions or more");
     for (int mu = 0; mu < c->ndim; ++mu)
       if (c->lat.L[mu] % 2 != 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: every lattice extent must be even");
   }
@@ -1737,7 +1765,9 @@ int bcg_dirac_hop_half(bcg_context* c, const bcg_gauge* g, bcg_field* out, const
   if (!c || !g || !out || !in || out == in || g->ctx != c || in->ctx != c || out->ctx != c || out->m != in->m || in->parity < 0 ||
       out->parity != 1 - in->parity)
     return BCG_ERR_INVALID;
-  bcg::launch_hop_half(c->stream, in->m, c->lat, out->parity, g->U, in->d, out->d, bcg::HOP_PLAIN, nullptr, 0.0);
+  BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
+  BCG_TRY(halo_field(c, in));
+  bcg::launch_hop_half(c->stream, in->m, c->lat, out->parity, g->U, g->Ughost, in->d, c->halo_recv, out->d, bcg::HOP_PLAIN, nullptr, 0.0);
   return check_launch(c, "hop_half");
 }
 

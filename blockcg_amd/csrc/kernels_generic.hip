@@ -223,6 +223,47 @@ __global__ void k_pack_faces(int m, LatticeDev lat, const double2* __restrict__ 
     dst[i] = f[site * row + e];
   }
 }
+// The faces of a half-volume field (sites of `parity` only; helpers below, "Half-volume fields"): face site f of the full
+// numbering (face_index) goes to f >> 1 -- the face's fastest coordinate (x0; x1 on the faces of direction 0) has an even
+// extent and alternates in parity -- so a half face is the first half of the full face's range and every offset of the
+// full message plan halves (the host posts the plan with half the bytes per site).
+__device__ __forceinline__ int64_t half_index(const LatticeDev& lat, const int x[4]);
+__global__ void k_pack_faces_half(int m, LatticeDev lat, int parity, const double2* __restrict__ f, double2* __restrict__ send) {
+  int mu = -1, k = blockIdx.y >> 1;
+  const int side = blockIdx.y & 1;
+  int64_t base_sites = 0;
+  for (int nu = 0; nu < lat.ndim; ++nu) {
+    if (!lat.split[nu]) continue;
+    if (k == 0) { mu = nu; break; }
+    --k;
+    base_sites += 2 * lat.face_sites[nu];
+  }
+  if (mu < 0) return;
+  const int row = 3 * m;
+  const int64_t half_face = lat.face_sites[mu] >> 1;
+  const int64_t n = half_face * row;
+  double2* dst = send + ((base_sites >> 1) + side * half_face) * row;
+  const int cn = mu == 0 ? 1 : 0;  // the coordinate the half face is compact in
+  const int o = lat.origin[0] + lat.origin[1] + lat.origin[2] + lat.origin[3];
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t hf = i / row;
+    const int e = static_cast<int>(i - hf * row);
+    int x[4];
+    int64_t fl = 2 * hf;
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      if (nu == mu) {
+        x[nu] = side ? lat.L[mu] - 1 : 0;
+      } else {
+        x[nu] = static_cast<int>(fl % lat.L[nu]);
+        fl /= lat.L[nu];
+      }
+    }
+    x[cn] += (x[0] + x[1] + x[2] + x[3] + parity + o) & 1;  // x[cn] is even here: the site of the pair that has the parity
+    dst[i] = f[half_index(lat, x) * row + e];
+  }
+}
 // gauge: only U_mu of the split direction mu itself, 9 complex per site
 __global__ void k_pack_gauge_faces(LatticeDev lat, const double2* __restrict__ U, double2* __restrict__ send) {
   int mu = -1, k = blockIdx.y >> 1;
@@ -348,10 +389,12 @@ __device__ __forceinline__ int64_t full_index(const LatticeDev& lat, const int x
 
 // out (parity p) = D in (parity 1 - p)   [HOP_PLAIN]   or   out = c0 * pfield - D in   [HOP_SHIFTED; pfield of parity p].
 // The arithmetic per site is k_hop_generic's, term for term (same results as the full-volume operator on that site).
-// Undivided lattices only (no ghost faces).
+// Across a split direction the neighbour comes from the HALF ghost face (k_pack_faces_half: face site f of the full
+// numbering lives at f >> 1, the ghost offsets are half the full ones), its link from the gauge ghost (full numbering).
 template <int M, int MODE>
 __global__ void __launch_bounds__(256) k_hop_half(LatticeDev lat, int parity, const double2* __restrict__ U,
-                                                  const double2* __restrict__ in, double2* __restrict__ out,
+                                                  const double2* __restrict__ Ughost, const double2* __restrict__ in,
+                                                  const double2* __restrict__ ghost, double2* __restrict__ out,
                                                   const double2* __restrict__ p, double c0) {
   constexpr int SPB = 256 / M;
   const int sl = threadIdx.x / M;
@@ -371,6 +414,14 @@ __global__ void __launch_bounds__(256) k_hop_half(LatticeDev lat, int parity, co
     const double2* pf = in + half_index(lat, xf) * 3 * M;
     const double2* pb = in + half_index(lat, xb) * 3 * M;
     const double2* ub = U + (full_index(lat, xb) * lat.ndim + mu) * 9;
+    if (lat.split[mu] && (x[mu] + 1 == lat.L[mu] || x[mu] == 0)) {
+      const int64_t fi = face_index(lat, x, mu);
+      if (x[mu] + 1 == lat.L[mu]) pf = ghost + ((lat.ghost_off[mu][1] >> 1) + (fi >> 1)) * 3 * M;
+      if (x[mu] == 0) {
+        pb = ghost + ((lat.ghost_off[mu][0] >> 1) + (fi >> 1)) * 3 * M;
+        ub = Ughost + (lat.ghost_off[mu][0] + fi) * 9;
+      }
+    }
     const double2* uf = U + (site * lat.ndim + mu) * 9;
     double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
 #pragma unroll
@@ -714,15 +765,22 @@ void launch_hop_generic(hipStream_t s, int m, const LatticeDev& lat, const doubl
   });
 }
 
-void launch_hop_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* U, const double2* in, double2* out,
-                     HopMode mode, const double2* p, double c0) {
+void launch_pack_faces_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* f, double2* send) {
+  const int ns = n_split(lat);
+  if (ns == 0) return;
+  hipLaunchKernelGGL(k_pack_faces_half, dim3(grid_for(max_face(lat) / 2 * 3 * m, 256, 4096), 2 * ns), dim3(256), 0, s, m, lat,
+                     parity, f, send);
+}
+
+void launch_hop_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* U, const double2* Ughost,
+                     const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0) {
   BCG_DISPATCH_M(m, {
     constexpr int SPB = 256 / M;
     const unsigned grid = static_cast<unsigned>((lat.V / 2 + SPB - 1) / SPB);
     if (mode == HOP_PLAIN)
-      hipLaunchKernelGGL((k_hop_half<M, HOP_PLAIN>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, in, out, p, c0);
+      hipLaunchKernelGGL((k_hop_half<M, HOP_PLAIN>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, Ughost, in, ghost, out, p, c0);
     else
-      hipLaunchKernelGGL((k_hop_half<M, HOP_SHIFTED>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, in, out, p, c0);
+      hipLaunchKernelGGL((k_hop_half<M, HOP_SHIFTED>), dim3(grid), dim3(SPB * M), 0, s, lat, parity, U, Ughost, in, ghost, out, p, c0);
   });
 }
 void launch_parity_copy(hipStream_t s, int m, const LatticeDev& lat, int parity, double2* full, double2* half, bool to_half) {

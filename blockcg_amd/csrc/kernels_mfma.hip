@@ -2107,7 +2107,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     };
     // CB: the links of the wave's SPW output sites of slice x3 -- every other site of a full-lattice row -- by LDS-DMA into
     // image(x3): forward links (one 36-entry record per site, the records 2 apart), then the backward links of all four
-    // directions, each U_mu of the full-lattice site x - mu (periodic; the lattice is undivided).
+    // directions, each U_mu of the full-lattice site x - mu (periodic, or across a divided direction 1..3 from the gauge
+    // ghost, which keeps the full-lattice face numbering: its offsets are twice the half faces' that `lat` carries).
     auto dma_links_cb = [&](int x3) __attribute__((always_inline)) {
       const int L0f = 2 * L0;
       const int rr = (x1 + x2 + x3 + win.cb_parity) & 1;           // x0 = 2 k + rr on this row
@@ -2127,15 +2128,26 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       const int64_t row1 = static_cast<int64_t>(L0f) * (x1m + static_cast<int64_t>(L1) * (x2 + static_cast<int64_t>(L2) * x3));
       const int64_t row2 = static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * (x2m + static_cast<int64_t>(L2) * x3));
       const int64_t row3 = static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * (x2 + static_cast<int64_t>(L2) * x3m));
+      // per direction: base of the row of 9-entry records the backward links come from, and the record stride in entries
+      // (a field row: 36-entry site records, U_mu at entry 9 mu; a ghost row: 9-entry records) -- wave-uniform
+      const char* const ug_ = reinterpret_cast<const char*>(Ughost);
+      const bool g1 = sp1 && x1 == 0, g2 = sp2 && x2 == 0, g3 = sp3 && x3 == 0;
+      const char* const b1 = g1 ? ug_ + (2 * static_cast<int64_t>(gm1) + static_cast<int64_t>(L0f) * (x2 + static_cast<int64_t>(L2) * x3)) * (9 * 16)
+                                : ub_ + (row1 * 4 + 1) * (9 * 16);
+      const char* const b2 = g2 ? ug_ + (2 * static_cast<int64_t>(gm2) + static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * x3)) * (9 * 16)
+                                : ub_ + (row2 * 4 + 2) * (9 * 16);
+      const char* const b3 = g3 ? ug_ + (2 * static_cast<int64_t>(gm3) + static_cast<int64_t>(L0f) * (x1 + static_cast<int64_t>(L1) * x2)) * (9 * 16)
+                                : ub_ + (row3 * 4 + 3) * (9 * 16);
+      const int t1 = g1 ? 9 * 16 : 36 * 16, t2 = g2 ? 9 * 16 : 36 * 16, t3 = g3 ? 9 * 16 : 36 * 16;
 #pragma unroll
       for (int k = 0; k < RBK; ++k) {
         const int e = lane + 64 * k;
         if (e < SPW * 9) {
           const int xs = xf0 + 2 * (e / 9);
           const unsigned eo = (e % 9) * 16;
-          glds16_link(ub_ + ((row1 + xs) * 4 + 1) * (9 * 16) + eo, img + (NFW + 64 * k) * 16);
-          glds16_link(ub_ + ((row2 + xs) * 4 + 2) * (9 * 16) + eo, img + (NFW + SPW * 9 + 64 * k) * 16);
-          glds16_link(ub_ + ((row3 + xs) * 4 + 3) * (9 * 16) + eo, img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
+          glds16_link(b1 + static_cast<int64_t>(xs) * t1 + eo, img + (NFW + 64 * k) * 16);
+          glds16_link(b2 + static_cast<int64_t>(xs) * t2 + eo, img + (NFW + SPW * 9 + 64 * k) * 16);
+          glds16_link(b3 + static_cast<int64_t>(xs) * t3 + eo, img + (NFW + 2 * SPW * 9 + 64 * k) * 16);
           const int xm = xs > 0 ? xs - 1 : L0f - 1;
           glds16_link(ub_ + ((rowf + xm) * 4 + 0) * (9 * 16) + eo, img + (NFW + 3 * SPW * 9 + 64 * k) * 16);
         }
@@ -3269,12 +3281,14 @@ static int launch_hop4(hipStream_t s, const LatticeDev& lat, const double2* U, c
   const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
   if (pl.list && grid == 0) return 0;  // no boundary tiles
   const int cls_t = pl.list ? 0 : cls;  // the list holds exactly the launch's tiles: no class filter in the kernel
-  // checkerboard form (half-volume fields): the bundle sweep at m = 16 on an undivided lattice, or nothing (the caller
-  // then runs the generic half-volume kernel)
+  // checkerboard form (half-volume fields): the bundle sweep at m = 16, 32 on a lattice whose direction 0 is not divided
+  // over ranks (lat: the compact lattice, with the half ghost faces' offsets), or nothing (the caller then runs the generic
+  // half-volume kernel)
   if (win.cb) {
     // m = 16 and 32: the widths with two link images per wave (the DMA needs the one that is not being read)
+    // (direction 0 divided: a compact row's end sites would read the ghost face in one row parity only -- not built)
     if (!hop4b_share_images(M) || (gram && M != 16) || mode == HOP_RESID || win.ring > 0 || cls != 0 || lat.split[0] ||
-        lat.split[1] || lat.split[2] || lat.split[3] || !bundle_ok(M, lat, tune, pl, cls, true))
+        !bundle_ok(M, lat, tune, pl, cls, true))
       return -1;
     constexpr int MC = hop4b_share_images(M) ? M : 16;  // (never launched for the other widths)
     HopWalk hwb = hw;

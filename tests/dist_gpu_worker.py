@@ -91,10 +91,58 @@ def main():
     for s in range(len(shifts)):
         e = rel(X[s].download(), local(o["X"][s]))
         assert e < 1e-11, ("X", s, rank, e)
+    if os.environ.get("BCG_TEST_HALF") == "1":
+        half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel)
     dist.barrier()
     if rank == 0:
         print("DIST_GPU_OK", world, grid, "generic" if generic else "fast", "op err %.2e" % e_op)
     dist.destroy_process_group()
+
+
+def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel):
+    """Half-volume fields on a lattice divided over ranks (half ghost faces: kernels_generic.hip k_pack_faces_half): the
+    operator blocks and the two-half-solves solve of this rank's sites against the whole-lattice oracle."""
+    L = ctx.local_dims
+    idx = np.arange(ctx.V)
+    par = np.zeros(ctx.V, dtype=np.int64)
+    for ext in L:  # x0 fastest; the local origin is even in every direction (even local extents)
+        par += idx % ext
+        idx = idx // ext
+    masks = [(par % 2) == q for q in (0, 1)]
+    Dh = local(orc.hop(U, gdims, Bh))
+    Ah = local(orc.dirac_apply(U, gdims, mass, Bh))
+    halves = B.split_parity()
+    ctx.profiling(True)
+    for q, half in enumerate(halves):
+        assert np.array_equal(half.download(), local(Bh)[masks[q]])
+        out = bc.block_fermion_field(ctx, m, parity=q)
+        D.op(out, half)
+        e = rel(out.download(), Ah[masks[q]])
+        assert e < 2e-13, ("half op", q, e)
+        other = bc.block_fermion_field(ctx, m, parity=1 - q)
+        D.D(other, half)
+        e = rel(other.download(), Dh[masks[1 - q]])
+        assert e < 2e-13, ("half D", q, e)
+    prof = ctx.profile()
+    ctx.profiling(False)
+    if os.environ.get("BCG_TEST_EXPECT_CHECKERBOARD") == "1":  # the bundle sweep's checkerboard form ran, ghost rows and all
+        assert prof.get("stencil_form_k_hop4b_checkerboard", {}).get("count", 0) >= 4, sorted(prof)
+    if comm.error:
+        raise comm.error
+    Gw = orc.hermitian_dot(Bh, Bh)
+    G = halves[0].hermitian_dot(halves[0]) + halves[1].hermitian_dot(halves[1])  # each all-reduced over the ranks
+    assert rel(G, Gw) < 1e-13
+    shifts, eps = [0.0, 1e-3, 5e-2], 1e-10
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    its = bc.SBCGrQ_half_volume(X, B, D, shifts, eps, eps)
+    if comm.error:
+        raise comm.error
+    ref = orc.sbcgrq(U, gdims, mass, Bh, shifts, eps, eps)
+    for s in range(len(shifts)):
+        e = rel(X[s].download(), local(ref["X"][s]))
+        assert e < 1e-8, ("half solve X", s, e)
+    assert max(its) <= ref["iterations"] + 1, (its, ref["iterations"])
+    assert bc.true_residuals(X, B, D, shifts).max() < 2 * eps  # the reference's acceptance test (test/solvers.cpp:104-116)
 
 
 if __name__ == "__main__":

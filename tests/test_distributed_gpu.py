@@ -42,7 +42,8 @@ def _sweep_mock_files():
         shutil.rmtree(d, ignore_errors=True)
 
 
-def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False, expect_ring_overlap=False):
+def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False, expect_ring_overlap=False,
+               half=False, expect_checkerboard=False):
     world = 1
     for g in grid:
         world *= g
@@ -53,6 +54,10 @@ def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overl
         env.update(BCG_TEST_TRANSPORT="native", BCG_RCCL_LIB=_mock_transport())
     if expect_ring_overlap:
         env.update(BCG_TEST_EXPECT_RING_OVERLAP="1")
+    if half:
+        env.update(BCG_TEST_HALF="1")
+    if expect_checkerboard:
+        env.update(BCG_TEST_EXPECT_CHECKERBOARD="1")
     port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
@@ -66,6 +71,27 @@ def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overl
 @pytest.mark.parametrize("dims,grid,m,generic", CASES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
 def test_domain_decomposed_solve(dims, grid, m, generic):
     _run_ranks(dims, grid, m, generic)
+
+
+HALF_CASES = [
+    # dims,            grid,          m,  generic, blocks, checkerboard bundle sweep expected
+    ([8, 4, 4, 8], [1, 1, 1, 2], 16, False, "8", False),     # x3 divided, generic half-volume kernel (row shorter than a tile pair)
+    ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False),      # 4 ranks, x0 (half faces compact in x1) and x1
+    ([4, 4, 8, 6], [1, 1, 2, 1], 3, True, "8", False),       # generic row kernels, x2
+    ([64, 16, 8, 6], [1, 2, 1, 1], 16, False, "32", True),   # checkerboard bundle sweep (compact row 32), ghost rows in x1
+    ([64, 8, 16, 12], [1, 1, 2, 2], 16, False, "32", True),  # ... in x2 and x3, 4 ranks
+    ([64, 8, 8, 6], [2, 1, 1, 1], 16, False, "32", False),   # x0 divided: the generic half-volume kernel (declared)
+    ([32, 16, 8, 4], [1, 2, 1, 1], 32, False, "32", True),   # m = 32
+]
+
+
+@pytest.mark.parametrize("dims,grid,m,generic,blocks,cb", HALF_CASES,
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_half_volume_fields_on_a_divided_lattice(dims, grid, m, generic, blocks, cb):
+    """SURVEY 8f-4 on the ladder: half-volume (parity-compact) fields with half ghost faces -- the operator blocks and the
+    two-half-solves solve of every rank's sites against the whole-lattice oracle (tests/dist_gpu_worker.py,
+    half_volume_checks), generic kernel and checkerboard bundle sweep."""
+    _run_ranks(dims, grid, m, generic, blocks=blocks, patch="16,2,2" if m == 16 else "8,2,2", half=True, expect_checkerboard=cb)
 
 
 RING_CASES = [
