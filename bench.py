@@ -175,9 +175,18 @@ def apply_config(args, world):
     return args
 
 
-def resolve_shape(world, local_dims, capacity):
+def resolve_shape(world, local_dims, capacity, half=False):
     """(sites per GPU, capacity ring, on-the-headline-ladder?) for a world size: the defaults documented at the top."""
     ladder = world > 1 and local_dims is None
+    if half:
+        # --half: the same ladder as two half-volume solves per GPU share (no ring: a half solve's 13 half fields + links are
+        # 188 GB at this share), the process grid growing over x3, x2, x1 with x0 -- the direction the half fields are
+        # compact in -- undivided: N = 2 128x64x64x128 (1,1,1,2), N = 4 128x64x128x128 (1,1,2,2), N = 8 128^4 (1,2,2,2)
+        if capacity:
+            sys.exit("--half: half-volume fields have no ring form (capacity mode)")
+        if local_dims is None:
+            local_dims = [128, 64, 64, 64] if world > 1 else [64, 64, 64, 64]
+        return list(local_dims), 0, ladder
     if local_dims is None:
         local_dims = [64, 64, 64, 128] if world > 1 else [64, 64, 64, 64]
     if capacity is None:
@@ -274,7 +283,8 @@ def plan_only(args, world, default_shape):
     os_, or_, nb = (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)(), (ctypes.c_size_t * 8)()
     ghost = ctypes.c_int64()
     cv = (ctypes.c_int * 4)(*(list(coords) + [0] * (4 - len(coords))))
-    n = lib.bcg_halo_plan(ndim, iv(gdims), iv(grid), cv, 3 * m * 16, ps, pr, os_, or_, nb, ctypes.byref(ghost))
+    # (half-volume fields: every face holds half its sites -- the same messages at half the bytes per site)
+    n = lib.bcg_halo_plan(ndim, iv(gdims), iv(grid), cv, 3 * m * 16 // (2 if args.half else 1), ps, pr, os_, or_, nb, ctypes.byref(ghost))
     assert n >= 0
     transport = os.environ.get("BCG_BACKEND", "rccl")
     overlapped = bool(args.capacity >= 4 and world > 1)  # every transport offers the split callbacks
@@ -283,6 +293,12 @@ def plan_only(args, world, default_shape):
     planned = ctypes.c_size_t()
     rc = lib.bcg_sbcgrq_plan_bytes(ndim, iv(gdims), iv(grid), m, S, 1, args.capacity, 1 if overlapped else 0, depth, ctypes.byref(planned))
     assert rc == 0, rc
+    if args.half:  # one half-volume solve at a time: every work field (X_s, P_s, Q, T, tmp, the further residual buffers) holds
+        # half the sites; links, face buffers and scratch stay (bcg_sbcgrq_device_bytes_half needs a context: same arithmetic)
+        V_local = 1
+        for l in args.local_dims:
+            V_local *= l
+        planned.value -= (2 * S + 3 + max(0, depth - 2)) * (V_local // 2) * 3 * m * 16
     mine = {"rank": rank, "coords": coords, "ghost_sites": ghost.value,
             "messages": [{"send_to": ps[k], "recv_from": pr[k], "send_offset": os_[k], "recv_offset": or_[k], "bytes": nb[k]} for k in range(n)],
             "device_bytes_planned": planned.value}
@@ -295,7 +311,7 @@ def plan_only(args, world, default_shape):
         out = {"plan_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "config": {"workload": f"SBCGrQ V={'x'.join(map(str, gdims))} ({'x'.join(map(str, args.local_dims))} per GPU), m={m}, {S} shifts",
                           "global_dims": gdims, "process_grid": grid, "m": m, "shifts": sorted(SHIFTS[:S]), "transport": transport,
-                          "headline_ladder": bool(default_shape and world > 1)},
+                          "headline_ladder": bool(default_shape and world > 1), "half_volume_solves": bool(args.half)},
                "capacity_ring_slices": args.capacity, "ring_overlapped": overlapped, "ring_chunk_slices": chunk,
                "ring_chunks": ([min(chunk, L3 - lo) for lo in range(0, L3, chunk)] if chunk else []),
                "shift_group_depth": depth, "device_bytes_planned": max(r["device_bytes_planned"] for r in ranks), "ranks": ranks}
@@ -308,6 +324,10 @@ def plan_only(args, world, default_shape):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--half", action="store_true",
+                    help="declared option (SURVEY 8f-4): the solve as two half-volume solves, one per site parity "
+                         "(dirac_op::D couples opposite parities only); a step = one iteration of each, timed as K "
+                         "iterations of the even solve + K of the odd one (one solve's fields alive at a time)")
     ap.add_argument("--steps", type=int, default=12)  # a multiple of the depth the shift updates are grouped over (4)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--local-dims", type=int, nargs="+", default=None,
@@ -337,7 +357,7 @@ def main():
     if os.environ.get("BCG_BENCH_TEST_HANG"):  # tests/test_bench_launcher.py: a rank that never finishes
         time.sleep(3600)
     default_shape = args.local_dims is None and args.capacity is None
-    args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity)
+    args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity, args.half)
 
     if args.plan_only:
         return plan_only(args, world, default_shape)
@@ -393,11 +413,6 @@ def main():
     m, S = args.m, args.shifts
     shifts = sorted(SHIFTS[:S])
     D = bc.dirac_op(ctx, MASS, seed=1)
-    B = bc.block_fermion_field(ctx, m).setRandom(seed=2)
-    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
-    st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0, consume_B=True)
-    st.iterate(args.warmup)
-    mem_free, mem_total = torch.cuda.mem_get_info(device)  # with every field of the solve alive
 
     def barrier():
         if dist is not None:
@@ -405,21 +420,33 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    ctx.profiling(True)
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    st.iterate(args.steps)          # EXACTLY K iterations; iterate() synchronizes the stream before returning
-    barrier()
-    dt = time.perf_counter() - t0
+    # one solve on all sites, or (--half) one per site parity, each timed over exactly K iterations between barriers
+    dt, bytes_in_use, residual = 0.0, 0, None
+    for par in ((0, 1) if args.half else (None,)):
+        B = bc.block_fermion_field(ctx, m, parity=par).setRandom(seed=2)
+        X = [bc.block_fermion_field(ctx, m, parity=par) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0, consume_B=True)
+        st.iterate(args.warmup)
+        mem_free, mem_total = torch.cuda.mem_get_info(device)  # with every field of the solve alive
+        bytes_in_use = max(bytes_in_use, mem_total - mem_free)
+        ctx.profiling(True)
+        if not par:
+            ctx.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        st.iterate(args.steps)          # EXACTLY K iterations; iterate() synchronizes the stream before returning
+        barrier()
+        dt += time.perf_counter() - t0
+        ctx.profiling(False)
+        residual = st.residual if residual is None else max(residual, st.residual)
+        if par == 0:  # the even solve's fields go before the odd solve's are made
+            st.end()
+            del st, X, B
     prof = ctx.profile()
-    ctx.profiling(False)
-    bytes_in_use = mem_total - mem_free
     if dist is not None:
         t = torch.tensor([dt, float(bytes_in_use)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, bytes_in_use = float(t[0].item()), int(t[1].item())
-    residual = st.residual
     n_comms = comm.communicators if transport == "rccl" else None  # 2: the split exchange has a communicator of its own
     st.end()
     if comm is not None and comm.error is not None:
@@ -435,7 +462,8 @@ def main():
         its = K / dt
         bytes_iter_total = ctx.bytes_per_iteration(m, S) * world
         hbm_gbps = bytes_iter_total * its / 1e9
-        roof = roofline_of(prof, list(args.local_dims), m, S, args.capacity, world)
+        # (--half: the PMC traffic file was taken on full-volume launches -- passing a world of 2 keeps it from being quoted)
+        roof = roofline_of(prof, list(args.local_dims), m, S, args.capacity, 2 if args.half else world)
         out = {
             "metric": "SBCGrQ lattice-site iterations/sec (iterations/sec x global volume), fp64",
             "value": Vg * its, "unit": "site-iter/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -446,7 +474,9 @@ def main():
                                    + ("; BASELINE configs[4] (m=32, 8 shifts) on the largest volume that fits 288 GB per GPU"
                                       if args.config == 4 else "")
                                    + ("; ladder to the 128^4 headline: N=1 64^4, N=2 64x64x128x128, N=4 64x128^3, N=8 128^4 "
-                                      "(64^3x128 per GPU, capacity ring 32)" if default_shape else ""),
+                                      "(64^3x128 per GPU, capacity ring 32)" if default_shape and not args.half else "")
+                                   + ("; --half: two half-volume solves (one per site parity), a step = one iteration of each"
+                                      if args.half else ""),
                        "global_dims": gdims, "process_grid": grid, "m": m, "shifts": shifts, "transport": transport,
                        "rccl_communicators": n_comms},
             "iterations_per_sec": its,
@@ -465,7 +495,8 @@ def main():
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("stencil_form_")},
             "stencil_kernel_launches": {k[len("stencil_form_"):]: v["count"] for k, v in prof.items() if k.startswith("stencil_form_")},
             "capacity_ring_slices": args.capacity,
-            "device_bytes_planned": ctx.sbcgrq_device_bytes(m, S, consume_B=True),
+            "device_bytes_planned": (ctx.sbcgrq_device_bytes_half(m, S, consume_B=True) if args.half
+                                     else ctx.sbcgrq_device_bytes(m, S, consume_B=True)),
             "device_bytes_in_use": bytes_in_use, "device_bytes_total": mem_total,  # max over ranks
             "comm_ms_per_iteration": {k: round(v["ms"] / K, 4) for k, v in prof.items()
                                       if k.startswith("halo_exchange") or k in ("allreduce", "pack_faces")} if world > 1 else None,

@@ -908,7 +908,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
       w.cb = 1;
       w.cb_parity = tmp->parity;
       {
-        ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2));
+        ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2), hop_flops(c, m, false, 1, 2));
         nb1 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0,
                                    c->partials, false, kFastBlocks, c->hop_tune, 0, w);
       }
@@ -921,7 +921,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
         if (fold) tune.fold = bcg::GramFold{c->dev_gram, c->fold_tickets};
         w.cb_parity = T->parity;
         {
-          ProfScope ps(c, gram ? "hop_half_shifted_gram" : "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2));
+          ProfScope ps(c, gram ? "hop_half_shifted_gram" : "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2), hop_flops(c, m, gram, 1, 2));
           nb2 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                      mass * mass + sigma0, c->partials, gram, kFastBlocks, tune, 0, w);
         }
@@ -936,13 +936,13 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
       }
     }
     {
-      ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2));
+      ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2), hop_flops(c, m, false, 1, 2));
       bcg::launch_hop_half(c->stream, m, c->lat, tmp->parity, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
     }
     BCG_TRY(check_launch(c, "hop_half"));
     BCG_TRY(halo_field(c, tmp));
     {
-      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2));
+      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2), hop_flops(c, m, false, 1, 2));
       bcg::launch_hop_half(c->stream, m, c->lat, T->parity, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                            mass * mass + sigma0);
     }

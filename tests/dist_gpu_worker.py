@@ -99,9 +99,19 @@ def main():
     dist.destroy_process_group()
 
 
-def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel):
+HALF_SHIFTS, HALF_EPS = [0.0, 1e-3, 5e-2], 1e-10
+
+
+def half_volume_oracle(orc, U, Bh, gdims, mass):
+    """What half_volume_checks compares with, on the whole lattice (computed once per process)."""
+    return {"Dh": orc.hop(U, gdims, Bh), "Ah": orc.dirac_apply(U, gdims, mass, Bh), "Gw": orc.hermitian_dot(Bh, Bh),
+            "ref": orc.sbcgrq(U, gdims, mass, Bh, HALF_SHIFTS, HALF_EPS, HALF_EPS)}
+
+
+def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel, pre=None):
     """Half-volume fields on a lattice divided over ranks (half ghost faces: kernels_generic.hip k_pack_faces_half): the
     operator blocks and the two-half-solves solve of this rank's sites against the whole-lattice oracle."""
+    pre = pre or half_volume_oracle(orc, U, Bh, gdims, mass)
     L = ctx.local_dims
     idx = np.arange(ctx.V)
     par = np.zeros(ctx.V, dtype=np.int64)
@@ -109,8 +119,8 @@ def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel):
         par += idx % ext
         idx = idx // ext
     masks = [(par % 2) == q for q in (0, 1)]
-    Dh = local(orc.hop(U, gdims, Bh))
-    Ah = local(orc.dirac_apply(U, gdims, mass, Bh))
+    Dh = local(pre["Dh"])
+    Ah = local(pre["Ah"])
     halves = B.split_parity()
     ctx.profiling(True)
     for q, half in enumerate(halves):
@@ -129,15 +139,15 @@ def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel):
         assert prof.get("stencil_form_k_hop4b_checkerboard", {}).get("count", 0) >= 4, sorted(prof)
     if comm.error:
         raise comm.error
-    Gw = orc.hermitian_dot(Bh, Bh)
+    Gw = pre["Gw"]
     G = halves[0].hermitian_dot(halves[0]) + halves[1].hermitian_dot(halves[1])  # each all-reduced over the ranks
     assert rel(G, Gw) < 1e-13
-    shifts, eps = [0.0, 1e-3, 5e-2], 1e-10
+    shifts, eps = HALF_SHIFTS, HALF_EPS
     X = [bc.block_fermion_field(ctx, m) for _ in shifts]
     its = bc.SBCGrQ_half_volume(X, B, D, shifts, eps, eps)
     if comm.error:
         raise comm.error
-    ref = orc.sbcgrq(U, gdims, mass, Bh, shifts, eps, eps)
+    ref = pre["ref"]
     for s in range(len(shifts)):
         e = rel(X[s].download(), local(ref["X"][s]))
         assert e < 1e-8, ("half solve X", s, e)

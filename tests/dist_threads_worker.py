@@ -41,6 +41,11 @@ def main():
     want_op = orc.dirac_apply(U, gdims, mass, Bh)
     want_G = orc.hermitian_dot(Bh, want_op)
     o = orc.sbcgrq(U, gdims, mass, Bh, shifts, 0.0, 0.0, max_iterations=iters, trace_limit=iters)
+    half = os.environ.get("BCG_TEST_HALF") == "1"  # and the half-volume fields on this grid (dist_gpu_worker.half_volume_checks)
+    if half:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from dist_gpu_worker import half_volume_checks, half_volume_oracle
+        half_pre = half_volume_oracle(orc, U, Bh, gdims, mass)
     orc.set_threads(1)
     uid = rccl.get_unique_id()
     errors, notes = [None] * world, [None] * world
@@ -87,6 +92,8 @@ def main():
             for s in range(len(shifts)):
                 e = rel(X[s].download(), local(o["X"][s]))
                 assert e < 1e-11, ("X", s, rank, e)
+            if half:
+                half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel, pre=half_pre)
             notes[rank] = (e_op, {k[len("stencil_form_"):]: v["count"] for k, v in prof.items() if k.startswith("stencil_form_")})
             comm.barrier()
             comm.close()

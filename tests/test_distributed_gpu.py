@@ -85,6 +85,11 @@ HALF_CASES = [
 ]
 
 
+def test_half_volume_fields_native_transport():
+    """The same over the native transport (stand-in for RCCL's calls): 4 ranks, x2 and x3 divided, checkerboard bundle sweep."""
+    _run_ranks([64, 8, 16, 12], [1, 1, 2, 2], 16, False, blocks="32", patch="16,2,2", half=True, expect_checkerboard=True, native=True)
+
+
 @pytest.mark.parametrize("dims,grid,m,generic,blocks,cb", HALF_CASES,
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
 def test_half_volume_fields_on_a_divided_lattice(dims, grid, m, generic, blocks, cb):
@@ -252,6 +257,30 @@ def test_bare_bench_command_starts_its_own_ranks(gpus):
     assert d["roofline"] and 0 < d["roofline"]["frac"] <= 1 and d["device_bytes_in_use"] > 0
 
 
+def test_bare_bench_command_half_volume_option():
+    """`python bench.py --gpus 4 --half`: two half-volume solves per step on the ladder's grid for half fields (x0, the
+    direction they are compact in, undivided: 4 ranks = (1,1,2,2)), native transport over the stand-in, checkerboard bundle
+    sweep with ghost rows."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32",
+               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--half", "--steps", "4", "--warmup", "1",
+           "--local-dims", "64", "8", "8", "6"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    _sweep_mock_files()
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["steps"] == 4 and d["value"] > 0 and d["capacity_ring_slices"] == 0
+    assert d["config"]["process_grid"] == [1, 1, 2, 2] and d["config"]["global_dims"] == [64, 8, 16, 12]
+    assert "two half-volume solves" in d["config"]["workload"]
+    assert d["stencil_kernel_launches"].get("k_hop4b_checkerboard", 0) == 2 * 2 * 4  # two launches x two parities x 4 iterations
+    comm = d["comm_ms_per_iteration"]
+    assert comm and comm["allreduce"] > 0 and comm["pack_faces"] > 0 and comm["halo_exchange"] > 0
+
+
 NATIVE_CASES = [
     # dims,             grid,          m,  ring, overlap (split exchange: second stream + events), blocks
     ([32, 4, 4, 8], [1, 1, 1, 2], 16, 0, True, "8"),     # x3 split over two ranks: + and - neighbour are the same peer
@@ -277,6 +306,7 @@ THREAD_CASES = [
     # global dims,       grid,          m,  ring
     ([32, 16, 8, 32], [2, 2, 2, 1], 16, 32),   # the headline's launch: ring 32 = L3, overlapped chunks of 15, 15 and 2 slices
     ([32, 16, 8, 24], [2, 2, 2, 1], 16, 0),    # whole tmp: interior + boundary launches with three divided directions
+    ([64, 16, 16, 12], [1, 2, 2, 2], 16, -1),  # `bench.py --gpus 8 --half`: half-volume fields, x0 (their compact direction) undivided
 ]
 
 
@@ -289,9 +319,13 @@ def test_headline_process_grid_eight_ranks_as_threads(dims, grid, m, ring):
     the native transport's stand-in in its synchronous mode (tests/dist_threads_worker.py); each rank checks operator, Gram
     matrix and a fixed-work solve against the whole-lattice oracle.  The bare 8-process launch of bench.py itself is
     rehearsed without GPUs in tests/test_bench_launcher.py::test_bare_headline_command_plans_eight_ranks."""
+    half = ring < 0  # the third case: full-volume checks without a ring, then the half-volume fields' (checkerboard bundle sweep
+    ring = max(ring, 0)  # with ghost rows in x1, x2 and x3, half faces, two half solves against the oracle's full solve)
     env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)), BCG_TEST_M=str(m),
                BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32", BCG_HOP_PATCH="16,2,2", BCG_MOCK_SYNC="1",
                BCG_RCCL_LIB=_mock_transport())
+    if half:
+        env.update(BCG_TEST_HALF="1", BCG_TEST_EXPECT_CHECKERBOARD="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_threads_worker.py")], env=env, capture_output=True,
                          text=True, timeout=1200)
     _sweep_mock_files()
