@@ -156,7 +156,9 @@ int bcg_field_width(const bcg_field* f);
  * sites each.  A half field holds the V/2 local sites of one parity (0 or 1) in the order of the full lattice; every
  * field primitive, dirac_apply and every solver accept half fields (all operands of a call of the SAME parity; the
  * solver's work fields are then half fields too: half the device memory of a full-volume solve, twice).
- * Undivided lattices with even extents only (BCG_ERR_UNSUPPORTED otherwise).  Links stay full-volume. */
+ * Even extents only (BCG_ERR_UNSUPPORTED otherwise).  Links stay full-volume.  On a lattice divided over ranks a half
+ * field's ghost faces hold half the sites: the library posts the same message plan as for a full field (bcg_halo_plan) with
+ * HALF the bytes per site, i.e. every offset and size halves; no capacity ring for half fields. */
 int bcg_field_create_half(bcg_context* ctx, int m, int parity, bcg_field** f);
 int bcg_field_parity(const bcg_field* f);   /* -1: full field; 0 / 1 */
 int64_t bcg_field_sites(const bcg_field* f); /* sites held: V_local or V_local / 2 */
