@@ -79,6 +79,15 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #ifndef BCG_HOP4B_SPREAD
 #define BCG_HOP4B_SPREAD 6
 #endif
+// BCAST: a link entry is read from the image ONCE per site -- the site's 72 entries of a step spread over the 16 lanes of a
+// row, 4.5 apiece, six ds_read_b128 per lane at the top of the step -- and reaches the FMAs of all 16 right-hand sides as the
+// broadcast operand of v_fmac_f64_dpp (row_newbcast:n = lane n of the lane's row of 16), instead of every lane reading every
+// entry (72 ds_read_b128 per lane and step: with the rows' 24 that was 3072 LDS-array cycles per CU and step against 2477 of
+// fp64 pipe -- the directions ran at the LDS array's rate, tools/microbench/fma_f64_issue.hip).  Same products, same order
+// along every accumulation chain: bit-identical.  -DBCG_HOP4B_BCAST=0: the per-lane reads (A/B build).
+#ifndef BCG_HOP4B_BCAST
+#define BCG_HOP4B_BCAST 1
+#endif
 #ifndef BCG_HOP4B_SPREAD_PLAIN
 #define BCG_HOP4B_SPREAD_PLAIN 0
 #endif
@@ -115,6 +124,13 @@ __device__ __forceinline__ dv2 ld_sv_async(const char* sbase, unsigned voff) {
 }
 // s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate is part of the instruction): until at most
 // the n YOUNGEST vector-memory operations of the wave are outstanding.  n above the table waits for everything (stricter).
+// acc += (+/-) u(lane LANE of this lane's row of 16) * p
+template <int LANE, bool NEG>
+__device__ __forceinline__ void fmac_bcast(double& acc, double u, double p) {
+  if (NEG) asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(p), "n"(LANE));
+  else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(p), "n"(LANE));
+}
+
 __device__ __forceinline__ void wait_vmcnt(int n) {
   switch (n) {
 #define BCG_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
@@ -2453,6 +2469,20 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       LU[S][3 + r] = (UB)[r * 3 + (K)];                                                                      \
     }                                                                                                        \
   }
+// BCAST: unit (MU, K), output colour R -- forward entry 9 MU + 3 K + R of the site's 36, backward entry 9 MU + 3 R + K (LQ below)
+#define BCG_FM1(MU, K, R, F, B)                                                                              \
+  {                                                                                                          \
+    constexpr int ef_ = 9 * (MU) + 3 * (K) + (R), eb_ = 9 * (MU) + 3 * (R) + (K);                            \
+    fmac_bcast<ef_ % 16, false>(t[R].x, LQ[ef_ / 16].x, F[K].x);                                             \
+    fmac_bcast<ef_ % 16, true>(t[R].x, LQ[ef_ / 16].y, F[K].y);                                              \
+    fmac_bcast<ef_ % 16, false>(t[R].y, LQ[ef_ / 16].x, F[K].y);                                             \
+    fmac_bcast<ef_ % 16, false>(t[R].y, LQ[ef_ / 16].y, F[K].x);                                             \
+    fmac_bcast<eb_ % 16, true>(t[R].x, LQ[3 + eb_ / 16].x, B[K].x);                                          \
+    fmac_bcast<eb_ % 16, true>(t[R].x, LQ[3 + eb_ / 16].y, B[K].y);                                          \
+    fmac_bcast<eb_ % 16, true>(t[R].y, LQ[3 + eb_ / 16].x, B[K].y);                                          \
+    fmac_bcast<eb_ % 16, false>(t[R].y, LQ[3 + eb_ / 16].y, B[K].x);                                         \
+  }
+#define BCG_FMB(MU, K, F, B) { BCG_FM1(MU, K, 0, F, B) BCG_FM1(MU, K, 1, F, B) BCG_FM1(MU, K, 2, F, B) }
 #define BCG_FM(S, K, F, B)                                                                                   \
   {                                                                                                          \
     _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
@@ -2472,7 +2502,14 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     const double eta = (par & 1) ? -1.0 : 1.0;                                                               \
     double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
     /* V0, V1: vector-memory instructions issued behind the first and the second unit (SPREAD), pinned by the barriers */ \
-    if (LNKAHEAD) {                                                                                          \
+    if (BCAST) {                                                                                             \
+      BCG_FMB(MU, 0, F, B)                                                                                   \
+      BCG_PIPE_SLOT(V0)                                                                                      \
+      BCG_FMB(MU, 1, F, B)                                                                                   \
+      BCG_PIPE_SLOT(V1)                                                                                      \
+      EXTRA                                                                                                  \
+      BCG_FMB(MU, 2, F, B)                                                                                   \
+    } else if (LNKAHEAD) {                                                                                   \
       BCG_LD(1 - (S0), 1, UFC, UBC)                                                                          \
       BCG_FM(S0, 0, F, B)                                                                                    \
       BCG_PIPE_SLOT(V0)                                                                                      \
@@ -2507,11 +2544,27 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
 #define BCG_PIPE_APART(text) asm volatile("; " text : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y))
         // (the shifted forms have p in flight besides: with the links a unit ahead they need 256 registers and spill 2-100 -- and a
         //  spilled destination of a hand-waited load is read before it arrives; tools/check_async_regs.py, run by the Makefile)
-        constexpr bool LNKAHEAD = MODE == HOP_PLAIN;
+        constexpr bool BCAST = BCG_HOP4B_BCAST != 0;
+        constexpr bool LNKAHEAD = MODE == HOP_PLAIN && !BCAST;
         dv2 LU[2][6];
         const dv2* const uf0 = Lf + (sw + 1) * 36;          // U_mu(x): + 9 mu
         const dv2* const ub0 = CB ? Lb + (3 * SPW + sw) * 9 : Lf + sw * 36;  // U_0(x - 0): the left neighbour's forward link (CB: gathered)
         const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
+        // BCAST: this lane's share of its site's links -- forward entries l + 16 q of the site's 36 (q = 0, 1, 2), backward
+        // entries l + 16 q of the 36 = 9 per direction (U_mu(x - mu), mu = 0 .. 3, wherever this step finds them), l = lane & 15;
+        // entries past the 36th repeat the last one (never used)
+        dv2 LQ[6];
+        if (BCAST) {
+          const int l16 = lane & 15;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int e = l16 + 16 * q < 36 ? l16 + 16 * q : 35;
+            LQ[q] = uf0[e];
+            const int d = e / 9, i = e - 9 * d;
+            const dv2* const ub = d == 0 ? ub0 : (d == 1 ? ub1 : (d == 2 ? ub2 : ub3));
+            LQ[3 + q] = ub[i];
+          }
+        }
         if (LNKAHEAD) BCG_LD(0, 0, uf0, ub0)
         __builtin_amdgcn_sched_barrier(0);
         BCG_PIPE_DIR(0, 0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG_LD_LP(lp1, Cp1), if (SP_B) BCG_ROW_PIECE(2), if (SP_B) BCG_ROW_PIECE(3))
@@ -2618,6 +2671,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         __builtin_amdgcn_sched_barrier(0);
 #undef BCG_LD
 #undef BCG_FM
+#undef BCG_FM1
+#undef BCG_FMB
 #undef BCG_PIPE_DIR
 #undef BCG_PIPE_SLOT
 #undef BCG_LD_LP
