@@ -77,17 +77,10 @@ HALF_CASES = [
     # dims,            grid,          m,  generic, blocks, checkerboard bundle sweep expected
     ([8, 4, 4, 8], [1, 1, 1, 2], 16, False, "8", False),     # x3 divided, generic half-volume kernel (row shorter than a tile pair)
     ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False),      # 4 ranks, x0 (half faces compact in x1) and x1
-    ([4, 4, 8, 6], [1, 1, 2, 1], 3, True, "8", False),       # generic row kernels, x2
-    ([64, 16, 8, 6], [1, 2, 1, 1], 16, False, "32", True),   # checkerboard bundle sweep (compact row 32), ghost rows in x1
-    ([64, 8, 16, 12], [1, 1, 2, 2], 16, False, "32", True),  # ... in x2 and x3, 4 ranks
+    ([64, 16, 16, 6], [1, 2, 2, 1], 16, False, "32", True),  # checkerboard bundle sweep (compact row 32), ghost rows in x1 and x2, 4 ranks
     ([64, 8, 8, 6], [2, 1, 1, 1], 16, False, "32", False),   # x0 divided: the generic half-volume kernel (declared)
     ([32, 16, 8, 4], [1, 2, 1, 1], 32, False, "32", True),   # m = 32
 ]
-
-
-def test_half_volume_fields_native_transport():
-    """The same over the native transport (stand-in for RCCL's calls): 4 ranks, x2 and x3 divided, checkerboard bundle sweep."""
-    _run_ranks([64, 8, 16, 12], [1, 1, 2, 2], 16, False, blocks="32", patch="16,2,2", half=True, expect_checkerboard=True, native=True)
 
 
 @pytest.mark.parametrize("dims,grid,m,generic,blocks,cb", HALF_CASES,
@@ -95,7 +88,8 @@ def test_half_volume_fields_native_transport():
 def test_half_volume_fields_on_a_divided_lattice(dims, grid, m, generic, blocks, cb):
     """SURVEY 8f-4 on the ladder: half-volume (parity-compact) fields with half ghost faces -- the operator blocks and the
     two-half-solves solve of every rank's sites against the whole-lattice oracle (tests/dist_gpu_worker.py,
-    half_volume_checks), generic kernel and checkerboard bundle sweep."""
+    half_volume_checks), generic kernel and checkerboard bundle sweep.  The native transport carries half fields in
+    test_bare_bench_command_half_volume_option (x2 and x3 divided) and in the 8-rank thread rehearsal (x1, x2, x3)."""
     _run_ranks(dims, grid, m, generic, blocks=blocks, patch="16,2,2" if m == 16 else "8,2,2", half=True, expect_checkerboard=cb)
 
 
