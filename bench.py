@@ -180,12 +180,13 @@ def resolve_shape(world, local_dims, capacity, half=False):
     ladder = world > 1 and local_dims is None
     if half:
         # --half: the same ladder as two half-volume solves per GPU share (no ring: a half solve's 13 half fields + links are
-        # 188 GB at this share), the process grid growing over x3, x2, x1 with x0 -- the direction the half fields are
-        # compact in -- undivided: N = 2 128x64x64x128 (1,1,1,2), N = 4 128x64x128x128 (1,1,2,2), N = 8 128^4 (1,2,2,2)
+        # 188 GB at this share), the process grid growing over x2 and x1 (comm.grid_for_half) with x0 -- the direction the half
+        # fields are compact in -- and x3 -- swept in chunks whose face exchanges overlap the stencil -- undivided:
+        # N = 2 128x64x64x128 (1,1,2,1), N = 4 128x128x64x128 (1,2,2,1), N = 8 128^4 (1,2,4,1)
         if capacity:
             sys.exit("--half: half-volume fields have no ring form (capacity mode)")
         if local_dims is None:
-            local_dims = [128, 64, 64, 64] if world > 1 else [64, 64, 64, 64]
+            local_dims = [128, 64, 32, 128] if world > 1 else [64, 64, 64, 64]
         return list(local_dims), 0, ladder
     if local_dims is None:
         local_dims = [64, 64, 64, 128] if world > 1 else [64, 64, 64, 64]
@@ -264,7 +265,7 @@ def plan_only(args, world, default_shape):
     bcg_sbcgrq_plan_bytes -- and rank 0 gathers them over the gloo control plane into one JSON line."""
     import ctypes
     from blockcg_amd import _lib
-    from blockcg_amd.comm import coords_of, grid_for
+    from blockcg_amd.comm import coords_of, grid_for, grid_for_half
     lib = _lib.load()
     rank = int(os.environ.get("RANK", "0"))
     ndim = len(args.local_dims)
@@ -272,7 +273,7 @@ def plan_only(args, world, default_shape):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")
-    grid = grid_for(world, ndim, keep_last=args.capacity > 0) if world > 1 else [1] * ndim
+    grid = (grid_for_half(world, ndim) if args.half else grid_for(world, ndim, keep_last=args.capacity > 0)) if world > 1 else [1] * ndim
     if os.environ.get("BCG_BENCH_GRID"):
         grid = [int(x) for x in os.environ["BCG_BENCH_GRID"].split(",")]
     coords = coords_of(rank, grid)
@@ -376,7 +377,7 @@ def main():
     transport = "none"
     if world > 1:
         import torch.distributed as dist
-        from blockcg_amd.comm import TorchDistComm, coords_of, grid_for
+        from blockcg_amd.comm import TorchDistComm, coords_of, grid_for, grid_for_half
         torch.cuda.set_device(device)
         transport = os.environ.get("BCG_BACKEND", "rccl")
         if transport not in ("rccl", "torch-nccl", "gloo"):
@@ -385,7 +386,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend="gloo")  # control plane only when transport == "rccl"
-        grid = grid_for(world, ndim, keep_last=args.capacity > 0)
+        grid = grid_for_half(world, ndim) if args.half else grid_for(world, ndim, keep_last=args.capacity > 0)
         if os.environ.get("BCG_BENCH_GRID"):  # rehearsal aid: an explicit process grid, e.g. "1,1,2,1"
             grid = [int(x) for x in os.environ["BCG_BENCH_GRID"].split(",")]
             assert len(grid) == ndim and int(__import__("math").prod(grid)) == world

@@ -33,6 +33,23 @@ def grid_for(world_size, ndim, keep_last=False):
     return grid
 
 
+def grid_for_half(world_size, ndim):
+    """The process grid of the half-volume ladder (bench.py --half): direction 0 -- the one half fields are compact in --
+    and the last direction -- swept in chunks whose exchanges overlap the stencil -- stay whole; the others halve in turn,
+    the slower one first: 2 -> (1,1,2,1), 4 -> (1,2,2,1), 8 -> (1,2,4,1)."""
+    if ndim < 4:
+        return grid_for(world_size, ndim)
+    grid = [1] * ndim
+    n, mu = world_size, ndim - 2
+    while n > 1:
+        if n % 2:
+            raise ValueError("world size must be a power of two")
+        grid[mu] *= 2
+        n //= 2
+        mu = mu - 1 if mu > 1 else ndim - 2
+    return grid
+
+
 def coords_of(rank, grid):
     c = []
     for g in grid:

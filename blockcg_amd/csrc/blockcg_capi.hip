@@ -435,19 +435,25 @@ int halo_field(bcg_context* c, const bcg_field* f, bool split = false) {
 // Faces of the x3 slices [x3_lo, x3_lo + x3_n) only; `d` is a whole field (ring = 0) or a ring of slices (capacity mode).
 // The other slices' ranges of the ghost buffer keep what they held.
 // x3b_n > 0: and those of a second range of slices, in the same exchange
+// parity >= 0: `d` is a half-volume field of that parity (whole, ring = 0): half faces, half the bytes per site (halo_field)
 int halo_window(bcg_context* c, int m, const double2* d, int x3_lo, int x3_n, int ring, bool split = false, int x3b_lo = 0,
-                int x3b_n = 0) {
+                int x3b_n = 0, int parity = -1) {
   if (!c->distributed) return BCG_OK;
   const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
   BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * site_bytes));
   {
     ProfScope ps(c, "pack_faces");
-    bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3_lo, x3_n, ring);
-    if (x3b_n > 0) bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3b_lo, x3b_n, ring);
+    if (parity >= 0) {
+      bcg::launch_pack_faces_half(c->stream, m, c->lat, parity, d, c->halo_send, x3_lo, x3_n);
+      if (x3b_n > 0) bcg::launch_pack_faces_half(c->stream, m, c->lat, parity, d, c->halo_send, x3b_lo, x3b_n);
+    } else {
+      bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3_lo, x3_n, ring);
+      if (x3b_n > 0) bcg::launch_pack_faces(c->stream, m, c->lat, d, c->halo_send, x3b_lo, x3b_n, ring);
+    }
   }
   BCG_TRY(check_launch(c, "pack_faces"));
   ProfScope ps(c, split ? "halo_exchange_begin" : "halo_exchange");
-  return exchange_faces(c, site_bytes, split, x3_lo, x3_n, x3b_lo, x3b_n);
+  return exchange_faces(c, parity >= 0 ? site_bytes / 2 : site_bytes, split, x3_lo, x3_n, x3b_lo, x3b_n);
 }
 
 // Capacity mode with overlapped exchanges: the received faces of slice x3 = 0 of every split direction, saved aside
@@ -757,21 +763,67 @@ int ensure_ring_scratch(bcg_context* c, int m) {
   }
   return BCG_OK;
 }
+// Half-volume fields on a lattice divided over ranks, direction 3 undivided: the same sweep in chunks of x3 slices on a WHOLE
+// tmp (half field; no ring), for the sake of its overlapped exchanges -- the faces of the source in two windows, those of tmp
+// chunk by chunk, each travelling while the neighbouring chunks are computed (apply_shifted_ring with half_tmp set).
+inline int half_chunk(const bcg_context* c) { return c->half_chunk_override > 0 ? c->half_chunk_override : 16; }
+inline bool half_chunked_path(const bcg_context* c) {
+  return c->distributed && can_overlap(c) && c->ndim == 4 && !c->lat.split[3] && !c->lat.split[0] && c->lat.L[3] > half_chunk(c);
+}
+int ensure_half_chunk_scratch(bcg_context* c, int m) {
+  BCG_TRY(ensure_scratch(c));
+  const int C = half_chunk(c), chunks = (c->lat.L[3] + C - 1) / C;
+  const size_t need = static_cast<size_t>(c->hop_tune.blocks > 0 ? c->hop_tune.blocks : kFastBlocks) * chunks * m * m * sizeof(double2);
+  if (m == 16 && need > c->partials_bytes) {  // the block partials of all chunks side by side, as in capacity mode
+    BCG_TRY(stream_sync(c));
+    (void)hipFree(c->partials);
+    c->partials = nullptr;
+    c->partials_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->partials, need));
+    c->partials_bytes = need;
+  }
+  return ensure_halo(c, static_cast<size_t>(c->ghost_sites) * 3 * m * sizeof(double2));
+}
 int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double sigma0, bcg_field* T, const bcg_field* P,
-                       int* gram_blocks) {
-  const int m = P->m, R = c->tmp_ring, L3 = c->lat.L[3];
+                       int* gram_blocks, bcg_field* half_tmp = nullptr) {
+  const bool half = half_tmp != nullptr;  // P, T: half fields of one parity, half_tmp: the whole tmp of the other
+  const int m = P->m, L3 = c->lat.L[3], R = half ? L3 : c->tmp_ring;
   // Overlapped form (ranks that exchange faces, split callbacks present, ring of at least 2 C + 2 slices): the exchange of
   // chunk k's tmp faces runs while the first stencil works on chunk k + 1 and the second one on chunk k - 1, so the ring
   // holds two chunks and the two boundary slices.  Otherwise C = R - 2 and every exchange is waited for where it is posted.
-  const bool overlap = ring_overlapped(c);
-  const int C = ring_chunk(c);
+  const bool overlap = half ? can_overlap(c) : ring_overlapped(c);
+  const int C = half ? half_chunk(c) : ring_chunk(c);
   BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
-  BCG_TRY(ensure_ring_scratch(c, m));
-  double2* const ring = c->tmp_ring_buf[m];
+  if (half) BCG_TRY(ensure_half_chunk_scratch(c, m));
+  else BCG_TRY(ensure_ring_scratch(c, m));
+  double2* const ring = half ? half_tmp->d : c->tmp_ring_buf[m];
   if (gram_blocks) *gram_blocks = 0;
   const bool gram = gram_blocks && m == 16;
   const bcg::HopTuning& tune = c->hop_tune;
-  const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2);
+  const size_t site_bytes = static_cast<size_t>(3) * m * sizeof(double2) / (half ? 2 : 1);  // (of the face messages)
+  // half fields: the compact lattice with the half ghost faces' offsets (apply_shifted), windows without ring addressing
+  bcg::LatticeDev lat = c->lat;
+  if (half) {
+    lat.L[0] /= 2;
+    lat.V /= 2;
+    for (int mu = 1; mu < 4; ++mu) lat.stride[mu] /= 2;
+    for (int mu = 0; mu < 4; ++mu) {
+      lat.face_sites[mu] /= 2;
+      lat.ghost_off[mu][0] /= 2;
+      lat.ghost_off[mu][1] /= 2;
+    }
+  }
+  const int par_p = half ? P->parity : -1, par_t = half ? half_tmp->parity : -1;
+  const int vden = half ? 2 * L3 : L3;  // a window's share of the full local volume
+  auto window = [&](int lo, int n, int parity_out) {
+    bcg::HopWindow w;
+    w.x3_lo = lo;
+    w.x3_n = n;
+    w.ring = half ? 0 : R;
+    w.cb = half ? 1 : 0;
+    w.cb_parity = half ? parity_out : 0;
+    return w;
+  };
   // The source's faces.  Serial form: one blocking exchange of the whole field.  Overlapped form: nothing blocks -- the
   // faces of the slices the first launches read (the wrap slice L3 - 1 and slices 0 .. C, tmp up to one slice past the
   // first chunk) go first, the rest behind them as a second outstanding exchange that travels while those launches run and is ended
@@ -779,9 +831,9 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   bool p_rest_pending = false;
   if (overlap && c->distributed) {
     const int n1 = (C + 1 < L3 - 1) ? C + 1 : L3 - 1;  // slices [0, n1) and slice L3 - 1
-    BCG_TRY(halo_window(c, m, P->d, 0, n1, 0, /*split=*/true, L3 - 1, 1));
+    BCG_TRY(halo_window(c, m, P->d, 0, n1, 0, /*split=*/true, L3 - 1, 1, par_p));
     if (n1 < L3 - 1) {
-      BCG_TRY(halo_window(c, m, P->d, n1, L3 - 1 - n1, 0, /*split=*/true));
+      BCG_TRY(halo_window(c, m, P->d, n1, L3 - 1 - n1, 0, /*split=*/true, 0, 0, par_p));
       p_rest_pending = true;
     }
     {
@@ -791,12 +843,17 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   } else {
     BCG_TRY(halo_field(c, P));
   }
-  if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/true));
+  // (a whole tmp keeps its slice 0: nothing is computed twice at the end of the sweep, no faces to put back)
+  if (overlap && !half) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/true));
   auto first = [&](int lo, int n) -> int {  // tmp[lo, lo+n) = D P
-    note_stencil_form(c, m, 0, bcg::HopWindow{lo, n, R}, /*plain=*/true);
-    ProfScope ps(c, "hop_ring", alg_bytes(c, m, 2, 1, n, L3), hop_flops(c, m, false, n, L3));
-    const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
-                                        0.0, c->partials, false, kFastBlocks, tune, 0, bcg::HopWindow{lo, n, R});
+    if (half) {
+      if (c->profiling) c->prof["stencil_form_k_hop4b_checkerboard"].count += 1;
+    } else {
+      note_stencil_form(c, m, 0, window(lo, n, 0), /*plain=*/true);
+    }
+    ProfScope ps(c, half ? "hop_half" : "hop_ring", alg_bytes(c, m, 2, 1, n, vden), hop_flops(c, m, false, n, vden));
+    const int nb = bcg::launch_hop_fast(c->stream, m, lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
+                                        0.0, c->partials, false, kFastBlocks, tune, 0, window(lo, n, par_t));
     if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
     return check_launch(c, "hop_ring");
   };
@@ -804,11 +861,12 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   int total = 0;
   auto second = [&](int lo, int hi) -> int {  // T[lo, hi) from tmp[lo - 1, hi]
     {
-      ProfScope ps(c, gram ? "hop_shifted_gram_ring" : "hop_shifted_ring", alg_bytes(c, m, 3, 1, hi - lo, L3),
-                   hop_flops(c, m, gram, hi - lo, L3));
-      const int nb = bcg::launch_hop_fast(c->stream, m, c->lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
+      if (half && c->profiling) c->prof["stencil_form_k_hop4b_checkerboard"].count += 1;
+      ProfScope ps(c, half ? (gram ? "hop_half_shifted_gram" : "hop_half_shifted") : (gram ? "hop_shifted_gram_ring" : "hop_shifted_ring"),
+                   alg_bytes(c, m, 3, 1, hi - lo, vden), hop_flops(c, m, gram, hi - lo, vden));
+      const int nb = bcg::launch_hop_fast(c->stream, m, lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                           c0, c->partials + static_cast<size_t>(total) * m * m, gram, kFastBlocks, tune, 0,
-                                          bcg::HopWindow{lo, hi - lo, R});
+                                          window(lo, hi - lo, par_p));
       if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
       total += nb;
     }
@@ -822,7 +880,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     const int hi = lo + C < L3 ? lo + C : L3;
     const int last = hi < L3 ? hi : L3 - 1;
     if (next <= last) BCG_TRY(first(next, last - next + 1));
-    if (hi == L3) {
+    if (hi == L3 && !half) {
       if (overlap) BCG_TRY(slice0_faces(c, site_bytes, /*save=*/false));
       else BCG_TRY(halo_window(c, m, P->d, 0, 1, 0));  // its P faces were replaced by tmp faces of the first chunk
       BCG_TRY(first(0, 1));
@@ -834,12 +892,12 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     for (int lo = 0; lo < L3; lo += C) {
       const int hi = lo + C < L3 ? lo + C : L3;
       BCG_TRY(stage_first(lo));
-      BCG_TRY(halo_window(c, m, ring, lo, hi - lo, R));
+      BCG_TRY(halo_window(c, m, ring, lo, hi - lo, half ? 0 : R, false, 0, 0, par_t));
       BCG_TRY(second(lo, hi));
     }
   } else {
     BCG_TRY(stage_first(0));
-    BCG_TRY(halo_window(c, m, ring, 0, (C < L3 ? C : L3), R, /*split=*/true));
+    BCG_TRY(halo_window(c, m, ring, 0, (C < L3 ? C : L3), half ? 0 : R, /*split=*/true, 0, 0, par_t));
     for (int lo = 0; lo < L3; lo += C) {
       const int hi = lo + C < L3 ? lo + C : L3;
       if (p_rest_pending) {  // the rest of the source's faces: posted before chunk 0's tmp faces, so ended before them
@@ -852,7 +910,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
         ProfScope ps(c, "halo_exchange_end");
         BCG_TRY(exchange_end(c));
       }
-      if (hi < L3) BCG_TRY(halo_window(c, m, ring, hi, (hi + C < L3 ? C : L3 - hi), R, /*split=*/true));
+      if (hi < L3) BCG_TRY(halo_window(c, m, ring, hi, (hi + C < L3 ? C : L3 - hi), half ? 0 : R, /*split=*/true, 0, 0, par_t));
       BCG_TRY(second(lo, hi));  // ... and chunk k + 1's faces fly while chunk k's T is computed
     }
   }
@@ -867,6 +925,7 @@ int reserve_operator_scratch(bcg_context* c, const bcg_field* like) {
   if (like->parity >= 0) {
     BCG_TRY(get_tmp_half(c, m, 1 - like->parity, &tmp));
     if (c->distributed) BCG_TRY(ensure_halo(c, static_cast<size_t>(c->ghost_sites) * 3 * m * sizeof(double2)));
+    if (half_chunked_path(c) && fast_hop(c, m)) BCG_TRY(ensure_half_chunk_scratch(c, m));
     return BCG_OK;
   }
   if (fast_hop(c, m)) BCG_TRY(ensure_scratch(c));
@@ -887,7 +946,6 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     bcg_field* tmp;
     BCG_TRY(get_tmp_half(c, m, 1 - P->parity, &tmp));
     BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
-    BCG_TRY(halo_field(c, P));  // (a lattice divided over ranks: the half faces of the source, then below those of tmp)
     // the bundle sweep in its checkerboard form (m = 16, compact row a multiple of the tile, patch walk), else the generic kernel
     bcg::LatticeDev latc = c->lat;
     latc.L[0] /= 2;
@@ -901,6 +959,14 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     // (direction 0 divided over ranks: the compact row's end sites would need the ghost face in one row parity only -- generic kernel)
     const bool fast = fast_hop(c, m) && (m == 16 || m == 32) && c->ndim == 4 && latc.L[0] > 0 && !c->lat.split[0] &&
                       bcg::hop_can_split_tiles(m, latc);
+    // direction 3 whole, split exchange available: the sweep in x3 chunks with every exchange overlapped
+    if (fast && half_chunked_path(c) && bcg::hop_kernel_form(m, latc, kFastBlocks, c->hop_tune, 0, bcg::HopWindow()) == 2) {
+      int nb = 0;
+      BCG_TRY(apply_shifted_ring(c, g, mass, sigma0, T, P, gram_blocks ? &nb : nullptr, tmp));
+      if (gram_blocks) *gram_blocks = nb;
+      return BCG_OK;
+    }
+    BCG_TRY(halo_field(c, P));  // (a lattice divided over ranks: the half faces of the source, then below those of tmp)
     int nb1 = -1, nb2 = -1;
     if (fast) {
       BCG_TRY(ensure_scratch(c));
@@ -1247,6 +1313,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_DEBUG_FIELD_BUDGET")) c->debug_field_budget = static_cast<size_t>(std::atoll(e));
   if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_HALF_CHUNK")) c->half_chunk_override = std::atoi(e);  // x3 chunk of the half-volume sweep (tests, tuning)
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);

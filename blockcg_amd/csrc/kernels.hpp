@@ -63,7 +63,8 @@ void launch_hop_generic(hipStream_t s, int m, const LatticeDev& lat, const doubl
 // (ghost: the half ghost faces of `in`, packed by launch_pack_faces_half -- per split mu [low face][high face], each
 // face_sites[mu] / 2 sites, face site f of the full numbering at f >> 1; Ughost: the gauge ghost, full numbering);
 // the copy between a full field and a half; the counter generator restricted to one parity.
-void launch_pack_faces_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* f, double2* send);
+void launch_pack_faces_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* f, double2* send,
+                            int x3_lo = 0, int x3_n = 0);  // x3_n > 0: those slices only, as launch_pack_faces
 void launch_hop_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* U, const double2* Ughost,
                      const double2* in, const double2* ghost, double2* out, HopMode mode, const double2* p, double c0);
 void launch_parity_copy(hipStream_t s, int m, const LatticeDev& lat, int parity, double2* full, double2* half, bool to_half);

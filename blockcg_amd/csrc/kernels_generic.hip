@@ -228,7 +228,10 @@ __global__ void k_pack_faces(int m, LatticeDev lat, const double2* __restrict__ 
 // extent and alternates in parity -- so a half face is the first half of the full face's range and every offset of the
 // full message plan halves (the host posts the plan with half the bytes per site).
 __device__ __forceinline__ int64_t half_index(const LatticeDev& lat, const int x[4]);
-__global__ void k_pack_faces_half(int m, LatticeDev lat, int parity, const double2* __restrict__ f, double2* __restrict__ send) {
+// x3_n > 0 (direction 3 undivided): the slices [x3_lo, x3_lo + x3_n) only -- x3 is the slowest face coordinate, so a
+// contiguous range of every half face, as for full fields.
+__global__ void k_pack_faces_half(int m, LatticeDev lat, int parity, const double2* __restrict__ f, double2* __restrict__ send,
+                                  int x3_lo, int x3_n) {
   int mu = -1, k = blockIdx.y >> 1;
   const int side = blockIdx.y & 1;
   int64_t base_sites = 0;
@@ -241,8 +244,10 @@ __global__ void k_pack_faces_half(int m, LatticeDev lat, int parity, const doubl
   if (mu < 0) return;
   const int row = 3 * m;
   const int64_t half_face = lat.face_sites[mu] >> 1;
-  const int64_t n = half_face * row;
-  double2* dst = send + ((base_sites >> 1) + side * half_face) * row;
+  const int64_t slice = x3_n > 0 ? half_face / lat.L[3] : 0;
+  const int64_t first = x3_n > 0 ? x3_lo * slice : 0;
+  const int64_t n = (x3_n > 0 ? x3_n * slice : half_face) * row;
+  double2* dst = send + ((base_sites >> 1) + side * half_face + first) * row;
   const int cn = mu == 0 ? 1 : 0;  // the coordinate the half face is compact in
   const int o = lat.origin[0] + lat.origin[1] + lat.origin[2] + lat.origin[3];
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
@@ -250,7 +255,7 @@ __global__ void k_pack_faces_half(int m, LatticeDev lat, int parity, const doubl
     const int64_t hf = i / row;
     const int e = static_cast<int>(i - hf * row);
     int x[4];
-    int64_t fl = 2 * hf;
+    int64_t fl = 2 * (first + hf);
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
       if (nu == mu) {
@@ -765,11 +770,14 @@ void launch_hop_generic(hipStream_t s, int m, const LatticeDev& lat, const doubl
   });
 }
 
-void launch_pack_faces_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* f, double2* send) {
+void launch_pack_faces_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* f, double2* send, int x3_lo,
+                            int x3_n) {
   const int ns = n_split(lat);
   if (ns == 0) return;
-  hipLaunchKernelGGL(k_pack_faces_half, dim3(grid_for(max_face(lat) / 2 * 3 * m, 256, 4096), 2 * ns), dim3(256), 0, s, m, lat,
-                     parity, f, send);
+  int64_t work = max_face(lat) / 2 * 3 * m;
+  if (x3_n > 0) work = work / lat.L[3] * x3_n;
+  hipLaunchKernelGGL(k_pack_faces_half, dim3(grid_for(work, 256, 4096), 2 * ns), dim3(256), 0, s, m, lat, parity, f, send, x3_lo,
+                     x3_n);
 }
 
 void launch_hop_half(hipStream_t s, int m, const LatticeDev& lat, int parity, const double2* U, const double2* Ughost,

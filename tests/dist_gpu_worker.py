@@ -104,8 +104,13 @@ HALF_SHIFTS, HALF_EPS = [0.0, 1e-3, 5e-2], 1e-10
 
 def half_volume_oracle(orc, U, Bh, gdims, mass):
     """What half_volume_checks compares with, on the whole lattice (computed once per process)."""
-    return {"Dh": orc.hop(U, gdims, Bh), "Ah": orc.dirac_apply(U, gdims, mass, Bh), "Gw": orc.hermitian_dot(Bh, Bh),
-            "ref": orc.sbcgrq(U, gdims, mass, Bh, HALF_SHIFTS, HALF_EPS, HALF_EPS)}
+    pre = {"Dh": orc.hop(U, gdims, Bh), "Ah": orc.dirac_apply(U, gdims, mass, Bh), "Gw": orc.hermitian_dot(Bh, Bh)}
+    # the oracle's own converged solve of the whole lattice is minutes of single-thread CPU per rank on the larger lattices:
+    # there the solve is judged by the reference's acceptance test alone (true residuals through the operator this worker has
+    # just checked against the oracle on the same decomposition)
+    if os.environ.get("BCG_TEST_HALF_ORACLE_SOLVE", "1") == "1":
+        pre["ref"] = orc.sbcgrq(U, gdims, mass, Bh, HALF_SHIFTS, HALF_EPS, HALF_EPS)
+    return pre
 
 
 def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel, pre=None):
@@ -137,6 +142,20 @@ def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel, 
     ctx.profiling(False)
     if os.environ.get("BCG_TEST_EXPECT_CHECKERBOARD") == "1":  # the bundle sweep's checkerboard form ran, ghost rows and all
         assert prof.get("stencil_form_k_hop4b_checkerboard", {}).get("count", 0) >= 4, sorted(prof)
+    if os.environ.get("BCG_TEST_EXPECT_HALF_CHUNKED") == "1":
+        # x3 whole and the split exchange on offer: the operator sweeps x3 in chunks (BCG_HALF_CHUNK) with every exchange --
+        # the source's faces in two windows, tmp's per chunk -- begun and ended around stencil launches, none blocking
+        ctx.profiling(True)
+        ctx.profile_reset()
+        out = bc.block_fermion_field(ctx, m, parity=0)
+        D.op(out, halves[0])
+        prof = ctx.profile()
+        ctx.profiling(False)
+        chunk = int(os.environ["BCG_HALF_CHUNK"])
+        chunks = (L[3] + chunk - 1) // chunk
+        assert "halo_exchange" not in prof, sorted(prof)
+        assert prof["halo_exchange_begin"]["count"] == chunks + 2 == prof["halo_exchange_end"]["count"], prof
+        assert prof["stencil_form_k_hop4b_checkerboard"]["count"] >= 2 * chunks, prof
     if comm.error:
         raise comm.error
     Gw = pre["Gw"]
@@ -147,11 +166,12 @@ def half_volume_checks(ctx, comm, orc, D, B, U, Bh, gdims, mass, m, local, rel, 
     its = bc.SBCGrQ_half_volume(X, B, D, shifts, eps, eps)
     if comm.error:
         raise comm.error
-    ref = pre["ref"]
-    for s in range(len(shifts)):
-        e = rel(X[s].download(), local(ref["X"][s]))
-        assert e < 1e-8, ("half solve X", s, e)
-    assert max(its) <= ref["iterations"] + 1, (its, ref["iterations"])
+    if "ref" in pre:
+        ref = pre["ref"]
+        for s in range(len(shifts)):
+            e = rel(X[s].download(), local(ref["X"][s]))
+            assert e < 1e-8, ("half solve X", s, e)
+        assert max(its) <= ref["iterations"] + 1, (its, ref["iterations"])
     assert bc.true_residuals(X, B, D, shifts).max() < 2 * eps  # the reference's acceptance test (test/solvers.cpp:104-116)
 
 

@@ -43,7 +43,7 @@ def _sweep_mock_files():
 
 
 def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overlap=True, native=False, expect_ring_overlap=False,
-               half=False, expect_checkerboard=False):
+               half=False, expect_checkerboard=False, half_chunk=0):
     world = 1
     for g in grid:
         world *= g
@@ -54,10 +54,12 @@ def _run_ranks(dims, grid, m, generic, ring=0, blocks="8", patch="16,2,2", overl
         env.update(BCG_TEST_TRANSPORT="native", BCG_RCCL_LIB=_mock_transport())
     if expect_ring_overlap:
         env.update(BCG_TEST_EXPECT_RING_OVERLAP="1")
-    if half:
-        env.update(BCG_TEST_HALF="1")
+    if half:  # (the oracle's converged whole-lattice solve only on the small lattices: dist_gpu_worker.half_volume_oracle)
+        env.update(BCG_TEST_HALF="1", BCG_TEST_HALF_ORACLE_SOLVE="1" if dims[0] * dims[1] * dims[2] * (dims[3] if len(dims) > 3 else 1) <= 4096 else "0")
     if expect_checkerboard:
         env.update(BCG_TEST_EXPECT_CHECKERBOARD="1")
+    if half_chunk:
+        env.update(BCG_HALF_CHUNK=str(half_chunk), BCG_TEST_EXPECT_HALF_CHUNKED="1")
     port = 29700 + (hash((tuple(dims), tuple(grid), m, ring)) % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
@@ -74,23 +76,25 @@ def test_domain_decomposed_solve(dims, grid, m, generic):
 
 
 HALF_CASES = [
-    # dims,            grid,          m,  generic, blocks, checkerboard bundle sweep expected
-    ([8, 4, 4, 8], [1, 1, 1, 2], 16, False, "8", False),     # x3 divided, generic half-volume kernel (row shorter than a tile pair)
-    ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False),      # 4 ranks, x0 (half faces compact in x1) and x1
-    ([64, 16, 16, 6], [1, 2, 2, 1], 16, False, "32", True),  # checkerboard bundle sweep (compact row 32), ghost rows in x1 and x2, 4 ranks
-    ([64, 8, 8, 6], [2, 1, 1, 1], 16, False, "32", False),   # x0 divided: the generic half-volume kernel (declared)
-    ([32, 16, 8, 4], [1, 2, 1, 1], 32, False, "32", True),   # m = 32
+    # dims,            grid,          m,  generic, blocks, checkerboard bundle sweep expected, x3 chunk (0: whole sweeps, blocking exchanges)
+    ([8, 4, 4, 8], [1, 1, 1, 2], 16, False, "8", False, 0),     # x3 divided, generic half-volume kernel (row shorter than a tile pair)
+    ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False, 0),      # 4 ranks, x0 (half faces compact in x1) and x1
+    ([64, 16, 16, 6], [1, 2, 2, 1], 16, False, "32", True, 0),  # checkerboard bundle sweep (compact row 32), ghost rows in x1 and x2, 4 ranks
+    ([64, 16, 8, 12], [1, 2, 1, 1], 16, False, "32", True, 5),  # the ladder's form: x3 whole, swept in chunks of 5, 5, 2 slices, exchanges overlapped
+    ([64, 8, 8, 6], [2, 1, 1, 1], 16, False, "32", False, 0),   # x0 divided: the generic half-volume kernel (declared)
+    ([32, 16, 8, 4], [1, 2, 1, 1], 32, False, "32", True, 0),   # m = 32
 ]
 
 
-@pytest.mark.parametrize("dims,grid,m,generic,blocks,cb", HALF_CASES,
+@pytest.mark.parametrize("dims,grid,m,generic,blocks,cb,chunk", HALF_CASES,
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, list) else str(v))
-def test_half_volume_fields_on_a_divided_lattice(dims, grid, m, generic, blocks, cb):
+def test_half_volume_fields_on_a_divided_lattice(dims, grid, m, generic, blocks, cb, chunk):
     """SURVEY 8f-4 on the ladder: half-volume (parity-compact) fields with half ghost faces -- the operator blocks and the
     two-half-solves solve of every rank's sites against the whole-lattice oracle (tests/dist_gpu_worker.py,
     half_volume_checks), generic kernel and checkerboard bundle sweep.  The native transport carries half fields in
     test_bare_bench_command_half_volume_option (x2 and x3 divided) and in the 8-rank thread rehearsal (x1, x2, x3)."""
-    _run_ranks(dims, grid, m, generic, blocks=blocks, patch="16,2,2" if m == 16 else "8,2,2", half=True, expect_checkerboard=cb)
+    _run_ranks(dims, grid, m, generic, blocks=blocks, patch="16,2,2" if m == 16 else "8,2,2", half=True, expect_checkerboard=cb,
+               half_chunk=chunk)
 
 
 RING_CASES = [
@@ -253,11 +257,11 @@ def test_bare_bench_command_starts_its_own_ranks(gpus):
 
 def test_bare_bench_command_half_volume_option():
     """`python bench.py --gpus 4 --half`: two half-volume solves per step on the ladder's grid for half fields (x0, the
-    direction they are compact in, undivided: 4 ranks = (1,1,2,2)), native transport over the stand-in, checkerboard bundle
-    sweep with ghost rows."""
+    direction they are compact in, and x3, swept in chunks with overlapped exchanges, undivided: 4 ranks = (1,2,2,1)),
+    native transport over the stand-in, checkerboard bundle sweep with ghost rows, chunks of 2 slices."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32",
-               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500")
+               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500", BCG_HALF_CHUNK="2")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--half", "--steps", "4", "--warmup", "1",
            "--local-dims", "64", "8", "8", "6"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -268,11 +272,13 @@ def test_bare_bench_command_half_volume_option():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["steps"] == 4 and d["value"] > 0 and d["capacity_ring_slices"] == 0
-    assert d["config"]["process_grid"] == [1, 1, 2, 2] and d["config"]["global_dims"] == [64, 8, 16, 12]
+    assert d["config"]["process_grid"] == [1, 2, 2, 1] and d["config"]["global_dims"] == [64, 16, 16, 6]
     assert "two half-volume solves" in d["config"]["workload"]
-    assert d["stencil_kernel_launches"].get("k_hop4b_checkerboard", 0) == 2 * 2 * 4  # two launches x two parities x 4 iterations
+    # per operator application: tmp[L3-1], then three chunks of two slices: 4 launches of the first stencil, 3 of the second
+    assert d["stencil_kernel_launches"].get("k_hop4b_checkerboard", 0) == 7 * 2 * 4  # x two parities x 4 iterations
     comm = d["comm_ms_per_iteration"]
-    assert comm and comm["allreduce"] > 0 and comm["pack_faces"] > 0 and comm["halo_exchange"] > 0
+    assert comm and comm["allreduce"] > 0 and comm["pack_faces"] > 0 and comm["halo_exchange_begin"] > 0
+    assert "halo_exchange" not in comm  # every exchange of the timed region in the split form
 
 
 NATIVE_CASES = [
