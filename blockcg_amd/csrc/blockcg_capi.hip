@@ -768,7 +768,9 @@ int ensure_ring_scratch(bcg_context* c, int m) {
 // chunk by chunk, each travelling while the neighbouring chunks are computed (apply_shifted_ring with half_tmp set).
 inline int half_chunk(const bcg_context* c) { return c->half_chunk_override > 0 ? c->half_chunk_override : 16; }
 inline bool half_chunked_path(const bcg_context* c) {
-  return c->distributed && can_overlap(c) && c->ndim == 4 && !c->lat.split[3] && !c->lat.split[0] && c->lat.L[3] > half_chunk(c);
+  // (half_chunk_force: BCG_HALF_CHUNK_FORCE=1, a tuning aid -- the chunked sweep on one GPU, to time what the chunks cost)
+  return ((c->distributed && can_overlap(c)) || c->half_chunk_force) && c->ndim == 4 && !c->lat.split[3] && !c->lat.split[0] &&
+         c->lat.L[3] > half_chunk(c);
 }
 int ensure_half_chunk_scratch(bcg_context* c, int m) {
   BCG_TRY(ensure_scratch(c));
@@ -1313,6 +1315,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_DEBUG_FIELD_BUDGET")) c->debug_field_budget = static_cast<size_t>(std::atoll(e));
   if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);
   if (const char* e = std::getenv("BCG_RING_OVERLAP")) c->ring_overlap = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BCG_HALF_CHUNK_FORCE")) c->half_chunk_force = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HALF_CHUNK")) c->half_chunk_override = std::atoi(e);  // x3 chunk of the half-volume sweep (tests, tuning)
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;

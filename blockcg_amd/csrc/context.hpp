@@ -76,6 +76,7 @@ struct bcg_context {
   size_t field_bytes_live = 0;           // bytes of the fields this context holds (incl. tmp and the solver's work fields)
   int debug_fail_iter = 0;               // test aid (BCG_DEBUG_FAIL_ITER): SBCGrQ iteration whose Gram matrix after phase B is made non-finite
   int ring_chunk_override = 0;           // capacity mode: chunk length in slices when smaller than the ring allows (BCG_RING_CHUNK)
+  bool half_chunk_force = false;         // BCG_HALF_CHUNK_FORCE: take the chunked half-volume sweep on an undivided lattice too (timing aid)
   int half_chunk_override = 0;           // > 0: x3 slices per chunk of the overlapped half-volume operator (BCG_HALF_CHUNK; default 16)
   bool ring_overlap = true;              // capacity mode: overlap the per-chunk exchanges when the callbacks allow (BCG_RING_OVERLAP)
   double2* partials = nullptr;           // block partials of Gram products
