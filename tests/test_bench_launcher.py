@@ -118,6 +118,30 @@ def test_roofline_picks_the_bound_that_binds_the_dominant_kernel(tmp_path):
     assert bench.roofline_of({}, [64] * 4, 16, 4, 0, 1) is None
 
 
+def test_half_volume_ladder_plans_eight_ranks():
+    """`python bench.py --gpus 8 --half --plan-only`: the declared half-volume ladder -- 128^4 as two half solves per GPU
+    share of 128 x 64 x 32 x 128 sites on a (1,2,4,1) grid (x0, which half fields are compact in, and x3, swept in chunks
+    with overlapped exchanges, stay whole), no ring, shift updates grouped over four iterations, half the bytes per face."""
+    import json
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--half", "--plan-only"], env=_clean_env(), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["plan_only"] and d["n_gpus"] == 8 and d["config"]["process_grid"] == [1, 2, 4, 1]
+    assert d["config"]["global_dims"] == [128] * 4 and d["config"]["half_volume_solves"]
+    assert d["capacity_ring_slices"] == 0 and d["shift_group_depth"] == 4
+    assert 185e9 < d["device_bytes_planned"] < 200e9  # 13 half fields of 12.9 GB + full links + faces: 284 GB in capacity mode
+    for r in d["ranks"]:
+        c = r["coords"]
+        assert c[0] == 0 and c[3] == 0 and r["rank"] == c[1] + 2 * c[2] and len(r["messages"]) == 4
+        f1, f2 = 128 * 32 * 128, 128 * 64 * 128  # sites of a face of direction 1, 2
+        assert [mm["bytes"] for mm in r["messages"]] == [f1 * 384, f1 * 384, f2 * 384, f2 * 384]  # 768 B per site, halved
+    for a in d["ranks"]:
+        for k, mm in enumerate(a["messages"]):
+            b = d["ranks"][mm["send_to"]]
+            assert b["messages"][k]["recv_from"] == a["rank"] and b["messages"][k]["bytes"] == mm["bytes"]
+
+
 def test_bare_headline_command_plans_eight_ranks():
     """`python bench.py --gpus 8 --plan-only`, typed bare as the round-end driver types the real command: the parent starts 8
     fresh rank processes (torch.distributed.run, gloo control plane), each derives its share with the library's host-side
