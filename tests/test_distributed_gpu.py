@@ -78,10 +78,9 @@ def test_domain_decomposed_solve(dims, grid, m, generic):
 HALF_CASES = [
     # dims,            grid,          m,  generic, blocks, checkerboard bundle sweep expected, x3 chunk (0: whole sweeps, blocking exchanges)
     ([8, 4, 4, 8], [1, 1, 1, 2], 16, False, "8", False, 0),     # x3 divided, generic half-volume kernel (row shorter than a tile pair)
-    ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False, 0),      # 4 ranks, x0 (half faces compact in x1) and x1
+    ([8, 8, 4, 4], [2, 2, 1, 1], 8, False, "8", False, 0),      # 4 ranks, x0 (half faces compact in x1; generic kernel, declared) and x1
     ([64, 16, 16, 6], [1, 2, 2, 1], 16, False, "32", True, 0),  # checkerboard bundle sweep (compact row 32), ghost rows in x1 and x2, 4 ranks
     ([64, 16, 8, 12], [1, 2, 1, 1], 16, False, "32", True, 5),  # the ladder's form: x3 whole, swept in chunks of 5, 5, 2 slices, exchanges overlapped
-    ([64, 8, 8, 6], [2, 1, 1, 1], 16, False, "32", False, 0),   # x0 divided: the generic half-volume kernel (declared)
     ([32, 16, 8, 4], [1, 2, 1, 1], 32, False, "32", True, 0),   # m = 32
 ]
 
@@ -306,7 +305,8 @@ THREAD_CASES = [
     # global dims,       grid,          m,  ring
     ([32, 16, 8, 32], [2, 2, 2, 1], 16, 32),   # the headline's launch: ring 32 = L3, overlapped chunks of 15, 15 and 2 slices
     ([32, 16, 8, 24], [2, 2, 2, 1], 16, 0),    # whole tmp: interior + boundary launches with three divided directions
-    ([64, 16, 16, 12], [1, 2, 2, 2], 16, -1),  # `bench.py --gpus 8 --half`: half-volume fields, x0 (their compact direction) undivided
+    ([64, 16, 16, 12], [1, 2, 2, 2], 16, -1),  # half-volume fields with x3 divided too: ghost rows of the checkerboard sweep in x1, x2, x3
+    ([64, 8, 16, 12], [1, 2, 4, 1], 16, -5),  # `bench.py --gpus 8 --half`: its grid (x0, x3 whole), x3 in chunks of 5, 5, 2, exchanges overlapped
 ]
 
 
@@ -319,13 +319,16 @@ def test_headline_process_grid_eight_ranks_as_threads(dims, grid, m, ring):
     the native transport's stand-in in its synchronous mode (tests/dist_threads_worker.py); each rank checks operator, Gram
     matrix and a fixed-work solve against the whole-lattice oracle.  The bare 8-process launch of bench.py itself is
     rehearsed without GPUs in tests/test_bench_launcher.py::test_bare_headline_command_plans_eight_ranks."""
-    half = ring < 0  # the third case: full-volume checks without a ring, then the half-volume fields' (checkerboard bundle sweep
-    ring = max(ring, 0)  # with ghost rows in x1, x2 and x3, half faces, two half solves against the oracle's full solve)
+    half = ring < 0  # full-volume checks without a ring, then the half-volume fields' (checkerboard bundle sweep with ghost
+    chunk = -ring if ring < -1 else 0  # rows, half faces, two half solves against the oracle's full solve); < -1: x3 chunk
+    ring = max(ring, 0)
     env = dict(os.environ, BCG_TEST_DIMS=",".join(map(str, dims)), BCG_TEST_GRID=",".join(map(str, grid)), BCG_TEST_M=str(m),
                BCG_TEST_RING=str(ring), OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32", BCG_HOP_PATCH="16,2,2", BCG_MOCK_SYNC="1",
                BCG_RCCL_LIB=_mock_transport())
     if half:
         env.update(BCG_TEST_HALF="1", BCG_TEST_EXPECT_CHECKERBOARD="1")
+    if chunk:  # (the oracle's converged solve is left to the case above: here the solve is judged by its true residuals)
+        env.update(BCG_HALF_CHUNK=str(chunk), BCG_TEST_EXPECT_HALF_CHUNKED="1", BCG_TEST_HALF_ORACLE_SOLVE="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_threads_worker.py")], env=env, capture_output=True,
                          text=True, timeout=1200)
     _sweep_mock_files()
