@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 #endif
 // PIPE: the software-pipelined schedule of the bundle sweep (m = 16, 32; full-lattice form): every global access of a step is
 // an operation hipcc does not see, issued where it pays and retired by hand-counted s_waitcnt -- see "PIPE" in hop4b_body.
-// -DBCG_HOP4B_PIPE=0 is the A/B build: the step of rounds 1-3 (still what m = 8, the checkerboard and the residual form run).
+// -DBCG_HOP4B_PIPE=0 is the A/B build: the step of rounds 1-3 (still what m = 8 and the residual form run).
 // The tuning builds of round 3 (the +x3 row by LDS-DMA, rows one step ahead, scheduling-barrier masks, write-through stores,
 // non-temporal link DMAs, the ablations of profiles/r03_stencil_ablation.txt, the carried-address check) have been removed:
 // their results are recorded in profiles/r03_stencil_*.txt and DESIGN_HISTORY.md, and PIPE supersedes what they explored.
@@ -2457,16 +2457,15 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
         const int x0 = CB ? 2 * (x0b + sw) + rr : x0b + sw;
         const int par1 = x0 + og0, par2 = par1 + x1 + og1, par3 = par2 + x2 + og2;
-// The links are read from the images three entries of U_mu(x) and three of U_mu(x - mu) at a time -- the six a "unit" (mu, k) of
-// 24 FMAs needs -- one unit AHEAD of their use (two register slots, LU[(3 mu + k) & 1]), written out in that order in the
-// source: hipcc, left alone, issues each ds_read right in front of the FMAs that use it (it schedules for register
-// pressure) and the wave sits out the LDS latency ten times per direction.  (Two units ahead does not fit 256 registers.)
-// The order of the FMAs along each accumulation chain is that of the other form: bit-identical results.
-#define BCG_LD(S, K, UF, UB)                                                                                 \
+// -DBCG_HOP4B_BCAST=0 (A/B build): every lane reads every link entry from the images, the six a unit (mu, k) of 24 FMAs needs
+// right in front of it.  (Round 4's first pipelined build read them a unit ahead in the plain form -- 48 registers of staging;
+// the broadcast form below needs neither.)  The order of the FMAs along each accumulation chain is the same in all forms:
+// bit-identical results.
+#define BCG_LD(K, UF, UB)                                                                                    \
   {                                                                                                          \
     _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
-      LU[S][r] = (UF)[(K) * 3 + r];                                                                          \
-      LU[S][3 + r] = (UB)[r * 3 + (K)];                                                                      \
+      LU[r] = (UF)[(K) * 3 + r];                                                                             \
+      LU[3 + r] = (UB)[r * 3 + (K)];                                                                         \
     }                                                                                                        \
   }
 // BCAST: unit (MU, K), output colour R -- forward entry 9 MU + 3 K + R of the site's 36, backward entry 9 MU + 3 R + K (LQ below)
@@ -2483,25 +2482,25 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     fmac_bcast<eb_ % 16, false>(t[R].y, LQ[3 + eb_ / 16].y, B[K].x);                                         \
   }
 #define BCG_FMB(MU, K, F, B) { BCG_FM1(MU, K, 0, F, B) BCG_FM1(MU, K, 1, F, B) BCG_FM1(MU, K, 2, F, B) }
-#define BCG_FM(S, K, F, B)                                                                                   \
+#define BCG_FM(K, F, B)                                                                                      \
   {                                                                                                          \
     _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
-      const dv2 u = LU[S][r];                                                                                \
+      const dv2 u = LU[r];                                                                                   \
       t[r].x = fma(u.x, F[K].x, t[r].x); t[r].x = fma(-u.y, F[K].y, t[r].x);                                 \
       t[r].y = fma(u.x, F[K].y, t[r].y); t[r].y = fma(u.y, F[K].x, t[r].y);                                  \
-      const dv2 v = LU[S][3 + r];                                                                            \
+      const dv2 v = LU[3 + r];                                                                               \
       t[r].x = fma(-v.x, B[K].x, t[r].x); t[r].x = fma(-v.y, B[K].y, t[r].x);                                \
       t[r].y = fma(-v.x, B[K].y, t[r].y); t[r].y = fma(v.y, B[K].x, t[r].y);                                 \
     }                                                                                                        \
   }
-// direction MU (S0: the slot of its unit 0 = MU & 1) with forward neighbour F, backward neighbour B; UFN / UBN: the next
-// direction's link pointers (unused if LAST); EXTRA: LDS reads the next direction needs, issued under this one's last unit
-#define BCG_PIPE_DIR(MU, S0, F, B, UFC, UBC, UFN, UBN, LAST, EXTRA, V0, V1)                                  \
+// direction MU with forward neighbour F, backward neighbour B, link pointers UF / UB (per-lane reads only); EXTRA: LDS
+// reads the next direction needs, issued under this one's last unit; V0, V1: vector-memory instructions issued behind the
+// first and the second unit (SPREAD), pinned by scheduling barriers
+#define BCG_PIPE_DIR(MU, F, B, UF, UB, EXTRA, V0, V1)                                                        \
   {                                                                                                          \
     const int par = (MU) == 0 ? 0 : ((MU) == 1 ? par1 : ((MU) == 2 ? par2 : par3));                         \
     const double eta = (par & 1) ? -1.0 : 1.0;                                                               \
     double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};                             \
-    /* V0, V1: vector-memory instructions issued behind the first and the second unit (SPREAD), pinned by the barriers */ \
     if (BCAST) {                                                                                             \
       BCG_FMB(MU, 0, F, B)                                                                                   \
       BCG_PIPE_SLOT(V0)                                                                                      \
@@ -2509,23 +2508,13 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       BCG_PIPE_SLOT(V1)                                                                                      \
       EXTRA                                                                                                  \
       BCG_FMB(MU, 2, F, B)                                                                                   \
-    } else if (LNKAHEAD) {                                                                                   \
-      BCG_LD(1 - (S0), 1, UFC, UBC)                                                                          \
-      BCG_FM(S0, 0, F, B)                                                                                    \
+    } else {                                                                                                 \
+      BCG_LD(0, UF, UB) BCG_FM(0, F, B)                                                                      \
       BCG_PIPE_SLOT(V0)                                                                                      \
-      BCG_LD(S0, 2, UFC, UBC)                                                                                \
-      BCG_FM(1 - (S0), 1, F, B)                                                                              \
-      BCG_PIPE_SLOT(V1)                                                                                      \
-      if (!(LAST)) BCG_LD(1 - (S0), 0, UFN, UBN)                                                             \
-      EXTRA                                                                                                  \
-      BCG_FM(S0, 2, F, B)                                                                                    \
-    } else { /* the form with the fused product has no registers to spare: each unit's links right in front of its FMAs */ \
-      BCG_LD(0, 0, UFC, UBC) BCG_FM(0, 0, F, B)                                                              \
-      BCG_PIPE_SLOT(V0)                                                                                      \
-      BCG_LD(0, 1, UFC, UBC) BCG_FM(0, 1, F, B)                                                              \
+      BCG_LD(1, UF, UB) BCG_FM(1, F, B)                                                                      \
       BCG_PIPE_SLOT(V1)                                                                                      \
       EXTRA                                                                                                  \
-      BCG_LD(0, 2, UFC, UBC) BCG_FM(0, 2, F, B)                                                              \
+      BCG_LD(2, UF, UB) BCG_FM(2, F, B)                                                                      \
     }                                                                                                        \
     _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
       acc[r].x = fma(eta, t[r].x, acc[r].x);                                                                 \
@@ -2545,8 +2534,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         // (the shifted forms have p in flight besides: with the links a unit ahead they need 256 registers and spill 2-100 -- and a
         //  spilled destination of a hand-waited load is read before it arrives; tools/check_async_regs.py, run by the Makefile)
         constexpr bool BCAST = BCG_HOP4B_BCAST != 0;
-        constexpr bool LNKAHEAD = MODE == HOP_PLAIN && !BCAST;
-        dv2 LU[2][6];
+        dv2 LU[6];
         const dv2* const uf0 = Lf + (sw + 1) * 36;          // U_mu(x): + 9 mu
         const dv2* const ub0 = CB ? Lb + (3 * SPW + sw) * 9 : Lf + sw * 36;  // U_0(x - 0): the left neighbour's forward link (CB: gathered)
         const dv2* const ub3 = Lb + (2 * SPW + sw) * 9;
@@ -2565,9 +2553,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
             LQ[3 + q] = ub[i];
           }
         }
-        if (LNKAHEAD) BCG_LD(0, 0, uf0, ub0)
         __builtin_amdgcn_sched_barrier(0);
-        BCG_PIPE_DIR(0, 0, f0, b0, uf0, ub0, uf0 + 9, ub1, false, BCG_LD_LP(lp1, Cp1), if (SP_B) BCG_ROW_PIECE(2), if (SP_B) BCG_ROW_PIECE(3))
+        BCG_PIPE_DIR(0, f0, b0, uf0, ub0, BCG_LD_LP(lp1, Cp1), if (SP_B) BCG_ROW_PIECE(2), if (SP_B) BCG_ROW_PIECE(3))
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
 #undef BCG_ROW_PIECE
@@ -2622,8 +2609,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         BCG_STAMPB(4)   // p loads and link DMAs issued
 #define BCG_C1 if (C_PIECES) { BCG_LINK_PIECE(0) }
 #define BCG_C2 if (C_PIECES) { BCG_LINK_PIECE(1) }
-        if (e1) { BCG_PIPE_DIR(1, 1, q1, lp1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, forward row outside the bundle"); }
-        else { BCG_PIPE_DIR(1, 1, lp1, q1, uf0 + 9, ub1, uf0 + 18, ub2, false, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, backward row outside the bundle"); }
+        if (e1) { BCG_PIPE_DIR(1, q1, lp1, uf0 + 9, ub1, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(1, lp1, q1, uf0 + 9, ub1, BCG_LD_LP(lp2, Cp2), BCG_C1, BCG_C2) BCG_PIPE_APART("direction 1, backward row outside the bundle"); }
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
 #undef BCG_C1
@@ -2650,8 +2637,8 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         BCG_STAMPB(6)   // next rows issued
 #define BCG_C3 if (C_PIECES) { BCG_LINK_PIECE(2) }
 #define BCG_C4 if (C_PIECES) { BCG_LINK_PIECE(3) }
-        if (e2) { BCG_PIPE_DIR(2, 0, q2, lp2, uf0 + 18, ub2, uf0 + 27, ub3, false, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
-        else { BCG_PIPE_DIR(2, 0, lp2, q2, uf0 + 18, ub2, uf0 + 27, ub3, false, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, backward row outside the bundle"); }
+        if (e2) { BCG_PIPE_DIR(2, q2, lp2, uf0 + 18, ub2, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, forward row outside the bundle"); }
+        else { BCG_PIPE_DIR(2, lp2, q2, uf0 + 18, ub2, , BCG_C3, BCG_C4) BCG_PIPE_APART("direction 2, backward row outside the bundle"); }
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
         if (SP_D) { BCG_NEXT_ROW("n2", n2, a_n2) }
@@ -2666,7 +2653,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
         BCG_STAMPB(8)   // wait for the +x3 row
 #pragma unroll
         for (int c = 0; c < 3; ++c) f3[c] = Cn[co + c * M];
-        BCG_PIPE_DIR(3, 1, f3, b3, uf0 + 27, ub3, uf0, ub0, true, , , )
+        BCG_PIPE_DIR(3, f3, b3, uf0 + 27, ub3, , , )
         BCG_PIPE_PIN;
         __builtin_amdgcn_sched_barrier(0);
 #undef BCG_LD
