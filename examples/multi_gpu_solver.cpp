@@ -3,12 +3,14 @@
 // domain-decomposed over several MI355X, ONE PROCESS PER GPU, with no Python anywhere: the drop-in headers over
 // libblockcg_hip.so, halo faces and the m x m all-reduce over libblockcg_rccl.so (RCCL, xGMI).
 //
-//   usage: multi_gpu_solver <idfile> L0 L1 L2 L3 G0 G1 G2 G3 [mass=0.1] [eps=1e-10] [capacity_ring=0]
+//   usage: multi_gpu_solver <idfile> L0 L1 L2 L3 G0 G1 G2 G3 [mass=0.1] [eps=1e-10] [capacity_ring=0] [half_volume=0]
 //     L = GLOBAL lattice extents, G = process grid (prod G = number of ranks).  Rank, world size and the local device
 //     come from RANK / WORLD_SIZE / LOCAL_RANK (set by tools/launch_ranks.sh, mpirun, srun or torch.distributed.run);
 //     <idfile> is a path all ranks can see, used once to hand RCCL's 128-byte unique id from rank 0 to the others.
 //   e.g. 8 GPUs, the BASELINE headline shape:
 //     tools/launch_ranks.sh 8 examples/_build/multi_gpu_solver /tmp/bcg.id 128 128 128 128 2 2 2 1 0.1 1e-10 16
+//   half_volume = 1: the same system as two half-volume solves, one per site parity (blockcg::SBCGrQ_half_volume; 192 GB
+//   per GPU at that shape without a ring -- keep directions 0 and 3 whole, e.g. grid 1 2 4 1: the exchanges then overlap)
 //
 // Build: see tests/test_cpp_dropin.py::test_multi_gpu_driver_builds (g++, -lblockcg_rccl -lblockcg_hip).
 #include <chrono>
@@ -31,7 +33,7 @@ int env_int(const char* name, int fallback) {
 
 int main(int argc, char** argv) {
   if (argc < 10) {
-    std::fprintf(stderr, "usage: %s <idfile> L0 L1 L2 L3 G0 G1 G2 G3 [mass] [eps] [capacity_ring]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <idfile> L0 L1 L2 L3 G0 G1 G2 G3 [mass] [eps] [capacity_ring] [half_volume]\n", argv[0]);
     return 2;
   }
   const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), device = env_int("LOCAL_RANK", 0);
@@ -53,6 +55,7 @@ int main(int argc, char** argv) {
   const double mass = argc > 10 ? std::atof(argv[10]) : 0.1;
   const double eps = argc > 11 ? std::atof(argv[11]) : 1e-10;
   const int ring = argc > 12 ? std::atoi(argv[12]) : 0;
+  const bool half_volume = argc > 13 && std::atoi(argv[13]) != 0;
   std::vector<double> shifts = {0.0, 1e-6, 1e-4, 1e-2};
 
   try {
@@ -76,7 +79,13 @@ int main(int argc, char** argv) {
     bcg_rccl_barrier(comm);
     const auto t0 = std::chrono::steady_clock::now();
     // :89-90.  In capacity mode the source's storage becomes the residual block (one field less in HBM) ...
-    const int iterations = ring > 0 ? blockcg::SBCGrQ_consuming_source(X, B, D, shifts, eps, eps) : SBCGrQ(X, B, D, shifts, eps, eps);
+    int iterations;
+    if (half_volume) {  // D couples opposite site parities only (inc/dirac_op.hpp:14-21): one solve per parity on half fields
+      const std::pair<int, int> its = blockcg::SBCGrQ_half_volume(X, B, D, shifts, eps, eps);
+      iterations = its.first > its.second ? its.first : its.second;
+    } else {
+      iterations = ring > 0 ? blockcg::SBCGrQ_consuming_source(X, B, D, shifts, eps, eps) : SBCGrQ(X, B, D, shifts, eps, eps);
+    }
     double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     bcg_rccl_max_double(comm, &seconds);
     if (ring > 0) B.setRandomDevice(2);  // ... so draw the same source again for the residual check

@@ -216,6 +216,26 @@ def test_multi_gpu_driver_two_ranks_same_idfile_twice(tmp_path):
 
 
 @pytest.mark.gpu
+def test_multi_gpu_driver_half_volume_two_ranks(tmp_path):
+    """The C++ driver's half-volume option on a lattice divided over two ranks (x1), x3 whole and swept in chunks of five
+    slices: blockcg::SBCGrQ_half_volume through the headers, half ghost faces and the overlapped exchanges through
+    libblockcg_rccl's split form (over the stand-in), residuals by the full-volume operator (benchmark.cpp:93-103)."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "blockcg_amd", "csrc"), "-s", "mock"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = _build_multi_gpu_driver("blockcg_rccl_mock")
+    env = dict(os.environ, BCG_LOCAL_RANK_OVERRIDE="0", BCG_HOP_BLOCKS="32", BCG_HOP_PATCH="16,2,2", BCG_HALF_CHUNK="5")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "launch_ranks.sh"), "2", exe, str(tmp_path / "bcg.id"), "64", "16", "8",
+                        "12", "1", "2", "1", "1", "0.3", "1e-9", "0", "1"], env=env, capture_output=True, text=True, timeout=300)
+    import glob
+    import shutil
+    for d in glob.glob("/dev/shm/bcg_mock_*"):
+        shutil.rmtree(d, ignore_errors=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = [float(x) for x in re.search(r"SBCGrQ residuals:\s+(.*)", r.stdout).group(1).split()]
+    assert len(res) == 4 and max(res) < 2e-9
+
+
+@pytest.mark.gpu
 def test_half_volume_solve_through_the_headers():
     """blockcg::SBCGrQ_half_volume (two solves on half fields, one per site parity) passes the reference's acceptance test
     evaluated with the full-volume operator."""
