@@ -2,7 +2,7 @@
 //
 // Host side of the hot path: this file holds the reference's control flow
 // (inc/block_solvers.hpp:91-185) and its m x m coefficient algebra; every loop over lattice sites
-// is a HIP kernel (kernels_generic.hip, kernels_mfma.hip).  There is no CPU fallback: without a
+// is a HIP kernel (kernels_generic.hip, kernels_mfma.hip, kernels_stencil.hip).  There is no CPU fallback: without a
 // gfx950 device bcg_context_create fails with BCG_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 // Generic (any supported block width) HIP kernels for gfx950: the complete hot path in plain VALU
 // form.  They are the product path for widths without an MFMA fast path (m = 1,2,3,4,6,12) and the
-// cross-check for the MFMA kernels (kernels_mfma.hip) at m = 8,16,32.
+// cross-check for the MFMA kernels (kernels_mfma.hip, kernels_stencil.hip) at m = 8,16,32.
 //
 // One thread per OUTPUT complex element everywhere, so global loads/stores are 16 B per lane and
 // consecutive lanes touch consecutive addresses (the device layout keeps a (site,colour) row of m

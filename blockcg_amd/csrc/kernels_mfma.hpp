@@ -1,4 +1,4 @@
-// Launchers of the MFMA fast path (kernels_mfma.hip); see that file for the data ownership scheme.
+// Launchers of the MFMA fast path (kernels_mfma.hip: row kernels, with the data ownership scheme; kernels_stencil.hip: the stencil).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@ bool mfma_rows_width(int m);    // widths whose right-multiplications (phase C, 
 bool hop_fast_width(int m);     // widths served by the LDS-staged stencil kernel (8, 16, 32)
 int phaseC_max_shifts(int m, bool applies_rinv);  // shifts one phase-C launch can take (LDS budget; Rinv takes a slot)
 
-// Gram partials folded inside the producing kernel (kernels_mfma.hip: gram_fold): the last block to finish sums the block
+// Gram partials folded inside the producing kernel (mfma_common.hpp: gram_fold): the last block to finish sums the block
 // partials in a fixed order into `out`, so no reduction launch follows.  out = nullptr: off.  The partials buffer needs
 // room for 8 more entries than blocks; tickets: 9 words, zero before the first use (the kernel leaves them zero).
 struct GramFold {
@@ -40,7 +40,7 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
                      int max_blocks);
-// Pacing counters of the specialised stencil (kernels_mfma.hip, HopWalk::sync); owned by the context.
+// Pacing counters of the specialised stencil (kernels_stencil.hip, HopWalk::sync); owned by the context.
 struct HopSync {
   unsigned* counters = nullptr;  // 8 * stride, device memory
   int stride = 0;                // tiles per block the buffer has room for

@@ -336,7 +336,7 @@ def test_specialised_4d_stencil(bc, orc, m, dims, walk, blocks, monkeypatch):
 def test_stencil_x3_carry_path(bc, orc, blocks, monkeypatch):
     """Per-XCD patch walk with as many blocks per class as tiles per patch slice: every block then visits
     (tile, x3), (tile, x3+1), ... and takes its -x3 neighbours from the LDS ring and U_3(x-3) from the previous
-    link image (kernels_mfma.hip, k_hop4) instead of global memory."""
+    link image (kernels_stencil.hip, k_hop4) instead of global memory."""
     monkeypatch.setenv("BCG_HOP_WALK", "3")
     monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
