@@ -831,17 +831,38 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   // first chunk) go first, the rest behind them as a second outstanding exchange that travels while those launches run and is ended
   // in front of the first launch that reads it (the transport ends exchanges in the order they began).
   bool p_rest_pending = false;
+  // Split exchanges begun and not yet ended.  The transports keep FIFO state per begin (comm_rccl.cpp: begun / ended and
+  // the `arrived` events; TorchDistComm: its pending list), so an error return between a begin and its end must not leave
+  // an entry behind -- the next exchange on this context would pop the stale one and read ghosts before they arrive.
+  // Every error exit of this function therefore ends what it began (the context and its transport stay usable).
+  struct OutstandingExchanges {
+    bcg_context* c;
+    int n = 0;
+    ~OutstandingExchanges() {
+      const std::string why = c->err;
+      for (; n > 0; --n) (void)c->comm.halo_exchange_end(c->comm.user);
+      c->err = why;
+    }
+  } outstanding{c};
+  auto begin_window = [&](const double2* d, int lo, int n, int ring_slots, int b_lo, int b_n, int parity) -> int {
+    BCG_TRY(halo_window(c, m, d, lo, n, ring_slots, /*split=*/true, b_lo, b_n, parity));
+    if (c->distributed) outstanding.n += 1;
+    return BCG_OK;
+  };
+  auto end_oldest = [&]() -> int {
+    ProfScope ps(c, "halo_exchange_end");
+    BCG_TRY(exchange_end(c));
+    outstanding.n -= 1;
+    return BCG_OK;
+  };
   if (overlap && c->distributed) {
     const int n1 = (C + 1 < L3 - 1) ? C + 1 : L3 - 1;  // slices [0, n1) and slice L3 - 1
-    BCG_TRY(halo_window(c, m, P->d, 0, n1, 0, /*split=*/true, L3 - 1, 1, par_p));
+    BCG_TRY(begin_window(P->d, 0, n1, 0, L3 - 1, 1, par_p));
     if (n1 < L3 - 1) {
-      BCG_TRY(halo_window(c, m, P->d, n1, L3 - 1 - n1, 0, /*split=*/true, 0, 0, par_p));
+      BCG_TRY(begin_window(P->d, n1, L3 - 1 - n1, 0, 0, 0, par_p));
       p_rest_pending = true;
     }
-    {
-      ProfScope ps(c, "halo_exchange_end");
-      BCG_TRY(exchange_end(c));
-    }
+    BCG_TRY(end_oldest());
   } else {
     BCG_TRY(halo_field(c, P));
   }
@@ -899,20 +920,16 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     }
   } else {
     BCG_TRY(stage_first(0));
-    BCG_TRY(halo_window(c, m, ring, 0, (C < L3 ? C : L3), half ? 0 : R, /*split=*/true, 0, 0, par_t));
+    BCG_TRY(begin_window(ring, 0, (C < L3 ? C : L3), half ? 0 : R, 0, 0, par_t));
     for (int lo = 0; lo < L3; lo += C) {
       const int hi = lo + C < L3 ? lo + C : L3;
       if (p_rest_pending) {  // the rest of the source's faces: posted before chunk 0's tmp faces, so ended before them
-        ProfScope ps(c, "halo_exchange_end");
-        BCG_TRY(exchange_end(c));
+        BCG_TRY(end_oldest());
         p_rest_pending = false;
       }
       if (hi < L3) BCG_TRY(stage_first(hi));  // chunk k + 1's slices of tmp, while chunk k's faces are on the links
-      {
-        ProfScope ps(c, "halo_exchange_end");
-        BCG_TRY(exchange_end(c));
-      }
-      if (hi < L3) BCG_TRY(halo_window(c, m, ring, hi, (hi + C < L3 ? C : L3 - hi), half ? 0 : R, /*split=*/true, 0, 0, par_t));
+      BCG_TRY(end_oldest());
+      if (hi < L3) BCG_TRY(begin_window(ring, hi, (hi + C < L3 ? C : L3 - hi), half ? 0 : R, 0, 0, par_t));
       BCG_TRY(second(lo, hi));  // ... and chunk k + 1's faces fly while chunk k's T is computed
     }
   }
@@ -961,8 +978,23 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     // (direction 0 divided over ranks: the compact row's end sites would need the ghost face in one row parity only -- generic kernel)
     const bool fast = fast_hop(c, m) && (m == 16 || m == 32) && c->ndim == 4 && latc.L[0] > 0 && !c->lat.split[0] &&
                       bcg::hop_can_split_tiles(m, latc);
-    // direction 3 whole, split exchange available: the sweep in x3 chunks with every exchange overlapped
-    if (fast && half_chunked_path(c) && bcg::hop_kernel_form(m, latc, kFastBlocks, c->hop_tune, 0, bcg::HopWindow()) == 2) {
+    // direction 3 whole, split exchange available: the sweep in x3 chunks with every exchange overlapped -- provided the
+    // checkerboard bundle sweep takes EVERY window the chunked sweep launches (1, C and C + 1 slices and the last, shorter
+    // chunk).  The chunked sweep has no generic fallback once its first exchange is posted; a tuning that switches the
+    // bundle walk off (BCG_HOP_BUNDLE=0, an odd BCG_HOP_PATCH) or a slice too small for the grid lands in the blocking
+    // path below, which falls back to k_hop_half.
+    bool chunk_windows_ok = fast && half_chunked_path(c);
+    if (chunk_windows_ok) {
+      const int C = half_chunk(c), L3 = c->lat.L[3];
+      for (int n = 1; n <= std::min(C + 1, L3) && chunk_windows_ok; ++n) {
+        bcg::HopWindow w;
+        w.x3_lo = 0;
+        w.x3_n = n;
+        w.cb = 1;
+        chunk_windows_ok = bcg::hop_uses_bundle(m, latc, kFastBlocks, c->hop_tune, 0, w, /*plain=*/true);
+      }
+    }
+    if (chunk_windows_ok) {
       int nb = 0;
       BCG_TRY(apply_shifted_ring(c, g, mass, sigma0, T, P, gram_blocks ? &nb : nullptr, tmp));
       if (gram_blocks) *gram_blocks = nb;
@@ -1541,8 +1573,12 @@ int bcg_sbcgrq_plan_bytes(int ndim, const int* global_dims, const int* grid, int
   total += ring_slices > 0 ? field / L[3] * ring_slices : field;                          // tmp of dirac_op::op
   total += static_cast<size_t>(V) * ndim * 9 * sizeof(double2);                          // links
   total += static_cast<size_t>(ghost) * (2 * 3 * m + 9) * sizeof(double2);                // send + receive faces, ghost links
+  if (ring_slices > 0 && (ring_slices - 2) / 2 < 1) ring_overlapped = 0;
   if (ring_slices > 0 && ring_overlapped) total += static_cast<size_t>(ghost) / L[3] * 3 * m * sizeof(double2);  // saved slice-0 faces
   size_t partials = static_cast<size_t>(kMaxGramBlocks) * 32 * 32 * sizeof(double2);
+  // (a ring of 3 slices cannot hold two chunks: the library then runs the serial form whatever the callbacks offer --
+  //  ring_overlapped(c) -- and so does this plan; the partials term assumes the default stencil grid and no BCG_RING_CHUNK)
+  if (ring_slices > 0 && (ring_slices - 2) / 2 < 1) ring_overlapped = 0;
   if (ring_slices > 0 && m == 16) {  // capacity mode: the block partials of all chunks side by side (ensure_ring_scratch)
     const int C = ring_overlapped ? (ring_slices - 2) / 2 : ring_slices - 2;
     const int chunks = (L[3] + C - 1) / C;
@@ -2338,35 +2374,55 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
       return rc_;                \
     }                            \
   } while (0)
-  // T, Q (:109).  T is overwritten before it is read, so it is not initialised from B.
-  BEGIN_TRY(create_like(c, B, &st->T));
-  if (consume_B) {
-    st->Q = B;
-  } else {
-    BEGIN_TRY(create_like(c, B, &st->Q));
-    BEGIN_TRY(bcg_field_copy(st->Q, B));
+  // Every allocation the solve cannot do without comes FIRST and in one stretch -- T, Q (:109), the P_s (:117), then what
+  // the operator needs (tmp or the ring, face buffers, partials; the first iteration would otherwise allocate it lazily,
+  // and it must come before the optional residual buffers below: a solve that fits without them must not fail because
+  // they took the room) -- so that on a lattice divided over ranks the ranks can AGREE on the outcome before the first
+  // collective of the solve (the Gram all-reduce inside thinQR, :115): a rank that ran out of memory would otherwise leave
+  // its peers waiting in that all-reduce for ever.  With the agreement every rank returns from a failed begin, with
+  // nothing allocated, and the caller can try again with a smaller plan (bench.py steps its ladder down this way).
+  int alloc_rc = create_like(c, B, &st->T);  // T is overwritten before it is read, so it is not initialised from B
+  if (alloc_rc == BCG_OK) {
+    if (consume_B) st->Q = B;
+    else alloc_rc = create_like(c, B, &st->Q);
   }
+  for (int s = 0; s < n_shifts && alloc_rc == BCG_OK; ++s) alloc_rc = create_like(c, B, &st->P[s]);
+  if (alloc_rc == BCG_OK) alloc_rc = reserve_operator_scratch(c, B);
+  if (c->distributed && c->have_comm && c->comm.allreduce_sum) {
+    const std::string why = c->err;
+    (void)hipGetLastError();
+    double failed_ranks = alloc_rc == BCG_OK ? 0.0 : 1.0;
+    int rc_ = BCG_OK;
+    *reinterpret_cast<double*>(c->pin_gram) = failed_ranks;
+    if (hipMemcpyAsync(c->dev_gram, c->pin_gram, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc_ = BCG_ERR_HIP;
+    if (rc_ == BCG_OK && c->comm.allreduce_sum(c->comm.user, c->dev_gram, 1) != 0) rc_ = BCG_ERR_COMM;
+    if (rc_ == BCG_OK && (hipMemcpyAsync(c->pin_gram, c->dev_gram, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                          hipStreamSynchronize(c->stream) != hipSuccess))
+      rc_ = BCG_ERR_HIP;
+    if (rc_ == BCG_OK) failed_ranks = *reinterpret_cast<const double*>(c->pin_gram);
+    if (alloc_rc == BCG_OK && rc_ != BCG_OK) {
+      alloc_rc = rc_;
+      c->err = "SBCGrQ: the ranks could not agree on the outcome of their allocations (all-reduce failed)";
+    } else if (alloc_rc == BCG_OK && failed_ranks > 0.0) {
+      alloc_rc = BCG_ERR_HIP;
+      c->err = "SBCGrQ: another rank of the process grid could not allocate the solve's fields (hipErrorOutOfMemory there)";
+    } else {
+      c->err = why;
+    }
+  }
+  if (alloc_rc != BCG_OK) {
+    sbcgrq_release(st);
+    delete st;
+    return alloc_rc;
+  }
+  if (!consume_B) BEGIN_TRY(bcg_field_copy(st->Q, B));
   for (int s = 0; s < n_shifts; ++s) BEGIN_TRY(bcg_field_set_zero(X[s]));  // :111-113
   BEGIN_TRY(thin_qr(c, st->Q, st->delta));                                  // :115
   st->rho = st->delta;                                                      // :116
-  for (int s = 0; s < n_shifts; ++s) {                                      // :117
-    BEGIN_TRY(create_like(c, B, &st->P[s]));
-    BEGIN_TRY(bcg_field_copy(st->P[s], st->Q));
-  }
+  for (int s = 0; s < n_shifts; ++s) BEGIN_TRY(bcg_field_copy(st->P[s], st->Q));  // :117
 #undef BEGIN_TRY
   st->alpha_s.assign(n_shifts, Identity);  // :122
   st->beta_s.assign(n_shifts, Identity);   // :123
-  // What the first iteration would otherwise allocate lazily (tmp or the ring, face buffers, partials) comes BEFORE the
-  // optional residual buffers: a solve that fits without them must not fail because they took the room (the header's
-  // promise: a solve that cannot allocate them runs at a smaller depth).
-  {
-    int rc_ = reserve_operator_scratch(c, B);
-    if (rc_ != BCG_OK) {
-      sbcgrq_release(st);
-      delete st;
-      return rc_;
-    }
-  }
   st->depth = pair_shifts_depth(c, m, n_shifts);
   for (int k = 2; k < st->depth; ++k) {  // depth 2 needs none (T doubles as the second residual buffer)
     bcg_field* q = nullptr;

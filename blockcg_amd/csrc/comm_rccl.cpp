@@ -202,27 +202,6 @@ int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int w
   std::memcpy(&id, id_bytes, sizeof id);
   ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) return bail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r), BCG_ERR_COMM);
-  // One communicator per stream.  The split exchange lives on xfer_stream while the Gram all-reduce is enqueued on the
-  // context's stream; with ONE communicator RCCL would order the two launches against each other with an event of its
-  // own -- the next chunk's exchange silently queued behind a pending all-reduce, or the reverse.  ncclCommSplit with one
-  // colour duplicates the communicator (collective over all ranks, no second unique id to distribute); every rank takes
-  // the same path, so matching sends and receives always meet on the same communicator.  BCG_RCCL_SINGLE_COMM=1 keeps the
-  // round-3 behaviour (A/B on hardware).
-  const char* single = std::getenv("BCG_RCCL_SINGLE_COMM");
-  if (single && std::atoi(single) != 0) {
-    c->halo_comm = c->comm;
-  } else {
-    r = ncclCommSplit(c->comm, 0, rank, &c->halo_comm, nullptr);
-    if (r == ncclSuccess) {
-      c->halo_comm_own = true;
-    } else {
-      // Every rank makes the same collective call, so every rank ends up here together: the run goes on with ONE
-      // communicator for both streams (correct; RCCL then orders the two streams' launches itself), says so on stderr,
-      // and bcg_comm_rccl_communicators reports 1 -- bench.py prints it in its line.
-      std::fprintf(stderr, "blockcg_rccl: ncclCommSplit failed (%s): one communicator serves both streams\n", ncclGetErrorString(r));
-      c->halo_comm = c->comm;
-    }
-  }
   int lo = 0, hi = 0;  // numerically lower = higher priority
   if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
   if (hipStreamCreateWithPriority(&c->xfer_stream, hipStreamNonBlocking, hi) != hipSuccess ||
@@ -231,6 +210,35 @@ int bcg_comm_rccl_create(bcg_context* ctx, const void* id_bytes, int rank, int w
       hipEventCreateWithFlags(&c->arrived[1], hipEventDisableTiming) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->scratch), sizeof(double)) != hipSuccess)
     return bail("stream/event/scratch creation failed", BCG_ERR_HIP);
+  // One communicator per stream.  The split exchange lives on xfer_stream while the Gram all-reduce is enqueued on the
+  // context's stream; with ONE communicator RCCL would order the two launches against each other with an event of its
+  // own -- the next chunk's exchange silently queued behind a pending all-reduce, or the reverse.  ncclCommSplit with one
+  // colour duplicates the communicator (collective over all ranks, no second unique id to distribute).
+  // BCG_RCCL_SINGLE_COMM=1 keeps the round-3 behaviour (A/B on hardware).
+  const char* single = std::getenv("BCG_RCCL_SINGLE_COMM");
+  if (single && std::atoi(single) != 0) {
+    c->halo_comm = c->comm;
+  } else {
+    r = ncclCommSplit(c->comm, 0, rank, &c->halo_comm, nullptr);
+    if (r == ncclSuccess) c->halo_comm_own = true;
+    else std::fprintf(stderr, "blockcg_rccl: rank %d: ncclCommSplit failed (%s)\n", rank, ncclGetErrorString(r));
+    // The ranks AGREE on the outcome over the first communicator: a split that failed on one rank only (a local
+    // allocation, say) must not leave that rank posting its split exchanges on `comm` while its peers post theirs on
+    // their `halo_comm` -- the sends and receives would never meet and the job would hang at the first overlapped
+    // exchange.  If any rank failed, every rank drops its second communicator: the run goes on with ONE communicator for
+    // both streams (correct; RCCL then orders the two streams' launches itself), says so on stderr, and
+    // bcg_comm_rccl_communicators reports 1 -- bench.py prints it in its line.
+    double failed = c->halo_comm_own ? 0.0 : 1.0;
+    if (bcg_rccl_sum_double(c, &failed) != BCG_OK) return bail("agreeing on the second communicator failed", BCG_ERR_COMM);
+    if (failed > 0.0) {
+      if (c->halo_comm_own && c->halo_comm) (void)ncclCommDestroy(c->halo_comm);
+      c->halo_comm_own = false;
+      c->halo_comm = c->comm;
+      if (rank == 0)
+        std::fprintf(stderr, "blockcg_rccl: ncclCommSplit failed on %d of %d ranks: one communicator serves both streams\n",
+                     static_cast<int>(failed), world);
+    }
+  }
   c->table.user = c;
   c->table.halo_exchange = cb_halo;
   c->table.allreduce_sum = cb_allreduce;
@@ -245,15 +253,61 @@ const bcg_comm* bcg_comm_rccl_callbacks(const bcg_rccl_comm* c) { return c ? &c-
 
 int bcg_comm_rccl_communicators(const bcg_rccl_comm* c) { return !c ? 0 : (c->halo_comm_own ? 2 : 1); }
 
-int bcg_rccl_max_double(bcg_rccl_comm* c, double* v) {
+namespace {
+int reduce_double(bcg_rccl_comm* c, double* v, ncclRedOp_t op) {
   if (!c || !v) return BCG_ERR_INVALID;
   if (hipMemcpyAsync(c->scratch, v, sizeof(double), hipMemcpyHostToDevice, c->ctx_stream) != hipSuccess) return BCG_ERR_HIP;
-  ncclResult_t r = ncclAllReduce(c->scratch, c->scratch, 1, ncclDouble, ncclMax, c->comm, c->ctx_stream);
+  ncclResult_t r = ncclAllReduce(c->scratch, c->scratch, 1, ncclDouble, op, c->comm, c->ctx_stream);
   if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return BCG_ERR_COMM; }
   if (hipMemcpyAsync(v, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->ctx_stream) != hipSuccess ||
       hipStreamSynchronize(c->ctx_stream) != hipSuccess)
     return BCG_ERR_HIP;
   return BCG_OK;
+}
+}  // namespace
+
+int bcg_rccl_max_double(bcg_rccl_comm* c, double* v) { return reduce_double(c, v, ncclMax); }
+int bcg_rccl_sum_double(bcg_rccl_comm* c, double* v) { return reduce_double(c, v, ncclSum); }
+
+// Every peer of the face exchange is contacted once on each communicator, with the Gram all-reduce in between: RCCL sets
+// up a peer's channel (and its device buffers) at the first transfer to it, not at ncclCommInitRank, so only after this
+// does the free device memory a launcher reads include what the transport takes.
+int bcg_rccl_warm_up(bcg_rccl_comm* c, int n_msgs, const int* peer_send, const int* peer_recv) {
+  if (!c || n_msgs < 0 || (n_msgs > 0 && (!peer_send || !peer_recv))) return BCG_ERR_INVALID;
+  struct RestoreDevice {
+    int prev = -1;
+    RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } restore_device;
+  if (hipSetDevice(c->device) != hipSuccess) return BCG_ERR_HIP;
+  for (int k = 0; k < n_msgs; ++k)
+    if (peer_send[k] < 0 || peer_send[k] >= c->world || peer_recv[k] < 0 || peer_recv[k] >= c->world) {
+      c->err = "bcg_rccl_warm_up: peer outside the communicator";
+      return BCG_ERR_INVALID;
+    }
+  char* buf = nullptr;  // [n_msgs] words out, [n_msgs] words in
+  const size_t word = 256;
+  if (n_msgs > 0 && hipMalloc(reinterpret_cast<void**>(&buf), 2 * word * n_msgs) != hipSuccess) return BCG_ERR_HIP;
+  int rc = BCG_OK;
+  ncclComm_t comms[2] = {c->comm, c->halo_comm};
+  hipStream_t streams[2] = {c->ctx_stream, c->xfer_stream};
+  for (int which = 0; which < (c->halo_comm_own ? 2 : 1) && rc == BCG_OK && n_msgs > 0; ++which) {
+    ncclResult_t bad = ncclGroupStart();
+    for (int k = 0; k < n_msgs && bad == ncclSuccess; ++k) {  // one word per message of the plan, in the plan's posting order
+      bad = ncclSend(buf + word * k, word, ncclChar, peer_send[k], comms[which], streams[which]);
+      if (bad == ncclSuccess) bad = ncclRecv(buf + word * (n_msgs + k), word, ncclChar, peer_recv[k], comms[which], streams[which]);
+    }
+    const ncclResult_t end = ncclGroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) {
+      c->err = std::string("bcg_rccl_warm_up: ") + ncclGetErrorString(bad != ncclSuccess ? bad : end);
+      rc = BCG_ERR_COMM;
+    }
+    if (rc == BCG_OK && hipStreamSynchronize(streams[which]) != hipSuccess) rc = BCG_ERR_HIP;
+  }
+  double one = 1.0;
+  if (rc == BCG_OK) rc = reduce_double(c, &one, ncclSum);
+  if (buf) (void)hipFree(buf);
+  return rc;
 }
 
 int bcg_rccl_barrier(bcg_rccl_comm* c) {

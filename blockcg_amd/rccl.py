@@ -24,6 +24,8 @@ SIGNATURES = {
     "bcg_comm_rccl_communicators": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_barrier": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_max_double": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "bcg_rccl_sum_double": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "bcg_rccl_warm_up": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bcg_comm_rccl_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "bcg_rccl_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
 }
@@ -97,6 +99,17 @@ class RcclComm:
         if self.lib.bcg_rccl_max_double(self.h, ctypes.byref(v)) != 0:
             raise RuntimeError(self.last_error())
         return v.value
+
+    def warm_up(self):
+        """One word to and from every peer of this rank's face exchange on each communicator, then an all-reduce: RCCL's
+        per-peer buffers exist afterwards, so the free device memory read next is what the solve can have (collective)."""
+        from .comm import halo_plan
+        msgs, _ = halo_plan(self.ctx.dims, self.ctx.grid, self.ctx.coords, 48)
+        n = len(msgs)
+        ps = (ctypes.c_int * max(n, 1))(*[mm[0] for mm in msgs])
+        pr = (ctypes.c_int * max(n, 1))(*[mm[1] for mm in msgs])
+        if self.lib.bcg_rccl_warm_up(self.h, n, ps, pr) != 0:
+            raise RuntimeError(self.last_error())
 
     def close(self):
         if getattr(self, "h", None) and self.ctx.h:

@@ -56,6 +56,12 @@ int bcg_comm_rccl_communicators(const bcg_rccl_comm* comm);
  * stream synchronize) and the maximum of a host double over all ranks. */
 int bcg_rccl_barrier(bcg_rccl_comm* comm);
 int bcg_rccl_max_double(bcg_rccl_comm* comm, double* value_inout);
+int bcg_rccl_sum_double(bcg_rccl_comm* comm, double* value_inout);
+/* Contact every peer of the face exchange once on each communicator and run one all-reduce, so that RCCL sets up its
+ * per-peer channels and device buffers NOW (it does so at the first transfer to a peer, not at ncclCommInitRank).  A
+ * launcher that sizes its run by the free device memory (bench.py's ladder) calls this first, with peer_send / peer_recv
+ * of bcg_halo_plan (one 256-byte word per message of the plan, in the plan's posting order).  Collective. */
+int bcg_rccl_warm_up(bcg_rccl_comm* comm, int n_msgs, const int* peer_send, const int* peer_recv);
 int bcg_comm_rccl_destroy(bcg_rccl_comm* comm);
 const char* bcg_rccl_last_error(const bcg_rccl_comm* comm); /* comm may be NULL: last creation error */
 

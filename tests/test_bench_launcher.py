@@ -118,6 +118,125 @@ def test_roofline_picks_the_bound_that_binds_the_dominant_kernel(tmp_path):
     assert bench.roofline_of({}, [64] * 4, 16, 4, 0, 1) is None
 
 
+def test_roofline_prices_the_stencil_family_and_the_pmc_rate(tmp_path):
+    """The two stencil applications of an iteration are two profile classes (hop, hop_shifted_gram) of one kernel template:
+    together they are the class with the most time, and `roofline` prices them together (launch-weighted), with every
+    member and the dominant single class beside it.  pmc_bytes_per_iteration: counters x launch counts, for the shape the
+    counters were taken at only and only when every class has an entry."""
+    import json
+    import pytest
+    bench = _bench_module()
+    prof = {
+        "hop": {"ms": 4 * 8.3, "count": 4, "bytes": 4 * 35.43e9, "flops": 4 * 0.155e12},
+        "hop_shifted_gram": {"ms": 4 * 10.8, "count": 4, "bytes": 4 * 48.32e9, "flops": 4 * 0.258e12},
+        "phaseC_multi4": {"ms": 57.1, "count": 1, "bytes": 257.7e9, "flops": 3.09e12},
+        "phaseC": {"ms": 33.2, "count": 3, "bytes": 3 * 64.4e9, "flops": 3 * 0.3e12},
+        "phaseB": {"ms": 29.8, "count": 4, "bytes": 4 * 38.65e9, "flops": 4 * 0.31e12},
+        "stencil_form_k_hop4b": {"ms": 0.0, "count": 8, "bytes": 0.0},
+    }
+    tj = tmp_path / "traffic.json"
+    tj.write_text(json.dumps({"hop": {"bytes_per_launch": 46.1e9}, "hop_shifted_gram": {"bytes_per_launch": 60.7e9},
+                              "phaseC_multi4": {"bytes_per_launch": 257.7e9}, "phaseC": {"bytes_per_launch": 64.5e9},
+                              "phaseB": {"bytes_per_launch": 38.7e9},
+                              "_shape": {"local_dims": [64] * 4, "m": 16, "n_shifts": 4, "capacity": 0}}))
+    r = bench.roofline_of(prof, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj))
+    assert r["kernel"] == "stencil family: hop + hop_shifted_gram" and r["bound"] == "hbm" and r["launches"] == 8
+    assert r["ms_in_timed_region"] == pytest.approx(4 * 19.1) and r["avg_launch_ms"] == pytest.approx(19.1 / 2)
+    assert r["achieved"] == pytest.approx((35.43e9 + 48.32e9) / 19.1e-3 / 1e9) and r["frac"] == pytest.approx(r["achieved"] / 8000.0)
+    assert r["traffic"] == pytest.approx((46.1e9 + 60.7e9) / 2) and r["algorithmic_bytes_per_launch"] == pytest.approx((35.43e9 + 48.32e9) / 2)
+    assert set(r["members"]) == {"hop", "hop_shifted_gram"} and r["members"]["hop"]["frac"] == pytest.approx(35.43e9 / 8.3e-3 / 1e9 / 8000)
+    assert r["dominant_single_class"]["kernel"] == "phaseC_multi4" and r["dominant_single_class"]["bound"] == "mfma"
+    assert bench.family_of("hop_shifted_gram_ring") == "stencil" and bench.family_of("phaseC") == "phaseC"
+    # the PMC rate of the whole iteration: K = 4 iterations in this profile
+    pmc = bench.pmc_bytes_per_iteration(prof, 4, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj))
+    assert pmc == pytest.approx((4 * 46.1e9 + 4 * 60.7e9 + 257.7e9 + 3 * 64.5e9 + 4 * 38.7e9) / 4)
+    assert bench.pmc_bytes_per_iteration(prof, 4, [64, 64, 64, 128], 16, 4, 32, 1, traffic_path=str(tj)) is None  # another shape
+    assert bench.pmc_bytes_per_iteration(prof, 4, [64] * 4, 16, 4, 0, 2, traffic_path=str(tj)) is None  # several ranks
+    prof["axpby"] = {"ms": 1.0, "count": 1, "bytes": 1e9, "flops": 0.0}  # a class the counters do not cover
+    assert bench.pmc_bytes_per_iteration(prof, 4, [64] * 4, 16, 4, 0, 1, traffic_path=str(tj)) is None
+
+
+def test_memory_ladder_rungs_and_plans():
+    """bench.memory_ladder / rung_plan (host arithmetic over bcg_sbcgrq_plan_bytes): the headline shape falls back through
+    ring 32 -> 16 -> 8 -> the half-volume form of the same lattice; an explicit shape has one rung unless --step-down; the
+    strong-scaling ladder has one."""
+    sys.path.insert(0, ROOT)
+    from blockcg_amd import _lib
+    bench = _bench_module()
+    lib = _lib.load()
+    rungs = bench.memory_ladder(8, [64, 64, 64, 128], 32, False, 16, True)
+    assert [r["label"] for r in rungs] == ["ring 32", "ring 16", "ring 8", "half-volume"]
+    assert [r["grid"] for r in rungs] == [[2, 2, 2, 1]] * 3 + [[1, 2, 4, 1]]
+    assert rungs[3]["local_dims"] == [128, 64, 32, 128] and rungs[3]["half"] and rungs[3]["capacity"] == 0
+    plans = [bench.rung_plan(lib, r, 8, 16, 4) for r in rungs]
+    assert all(p["gdims"] == [128] * 4 for p in plans)  # every rung is the SAME lattice
+    assert plans[0]["planned"] > plans[1]["planned"] > plans[2]["planned"] > plans[3]["planned"]
+    assert 288e9 < plans[0]["planned"] < 290e9 and 190e9 < plans[3]["planned"] < 195e9
+    assert (plans[0]["chunk"], plans[1]["chunk"], plans[2]["chunk"]) == (15, 7, 3) and plans[3]["depth"] == 4 and plans[0]["depth"] == 2
+    for n in (2, 4):
+        assert [r["label"] for r in bench.memory_ladder(n, [64, 64, 64, 128], 32, False, 16, True)][-1] == "half-volume"
+    assert len(bench.memory_ladder(1, [64] * 4, 0, False, 16, True)) == 1
+    assert len(bench.memory_ladder(4, [32, 8, 8, 16], 16, False, 16, False)) == 1
+    assert [r["label"] for r in bench.memory_ladder(4, [32, 8, 8, 16], 16, False, 16, False, step_down=True)] == ["ring 16", "ring 8", "half-volume"]
+    assert len(bench.memory_ladder(8, [64, 32, 32, 32], 0, False, 16, True, strong=True)) == 1
+    assert len(bench.memory_ladder(8, [128, 64, 32, 128], 0, True, 16, True)) == 1  # --half asked for: nothing below it
+
+
+@pytest.mark.parametrize("short_gb,rung,ring", [(2, "ring 16", 16), (5, "half-volume", 0)])
+def test_bare_headline_command_steps_down_the_memory_ladder(short_gb, rung, ring):
+    """`python bench.py --gpus 8 --plan-only` told (BCG_DEBUG_FIELD_BUDGET, the library's stand-in for a full device) that
+    the GPUs have `short_gb` GB less than ring 32 needs: the eight ranks agree on the next rung that fits, print it, and
+    plan THAT launch (grid, messages, bytes)."""
+    import json
+    sys.path.insert(0, ROOT)
+    from blockcg_amd import _lib
+    bench = _bench_module()
+    p32 = bench.rung_plan(_lib.load(), bench.memory_ladder(8, [64, 64, 64, 128], 32, False, 16, True)[0], 8, 16, 4)["planned"]
+    free = p32 + bench.RUNTIME_RESERVE - short_gb * 10 ** 9
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--plan-only"], env=_clean_env(BCG_DEBUG_FIELD_BUDGET=str(free)),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["memory_ladder_rung"] == rung and d["capacity_ring_slices"] == ring and d["config"]["global_dims"] == [128] * 4
+    notes = d["config"]["memory_ladder"]
+    assert notes[0]["rung"] == "ring 32" and "exceed" in notes[0]["verdict"] and notes[-1]["rung"] == rung and notes[-1]["verdict"] == "chosen"
+    assert all(n["free_bytes_min_over_ranks"] == free for n in notes)
+    assert d["device_bytes_planned"] + bench.RUNTIME_RESERVE <= free
+    assert d["config"]["process_grid"] == ([1, 2, 4, 1] if ring == 0 else [2, 2, 2, 1]) and d["config"]["half_volume_solves"] == (ring == 0)
+    assert len(d["ranks"]) == 8 and all(len(r["messages"]) == (4 if ring == 0 else 6) for r in d["ranks"])
+
+
+def test_memory_ladder_exhausted_is_an_error_not_a_hang():
+    """90 GB short is still the half-volume form; 100 GB short fits nothing: every rank exits non-zero with the reason."""
+    import json
+    sys.path.insert(0, ROOT)
+    from blockcg_amd import _lib
+    bench = _bench_module()
+    p32 = bench.rung_plan(_lib.load(), bench.memory_ladder(2, [64, 64, 64, 128], 32, False, 16, True)[0], 2, 16, 4)["planned"]
+    for short_gb, ok in ((90, True), (100, False)):
+        free = p32 + bench.RUNTIME_RESERVE - short_gb * 10 ** 9
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--plan-only"], env=_clean_env(BCG_DEBUG_FIELD_BUDGET=str(free)),
+                             capture_output=True, text=True, timeout=600)
+        if ok:
+            assert out.returncode == 0, out.stderr[-3000:]
+            d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+            assert d["config"]["memory_ladder_rung"] == "half-volume" and d["config"]["process_grid"] == [1, 1, 2, 1]
+        else:
+            assert out.returncode != 0 and "no rung of the memory ladder fits" in out.stderr
+
+
+def test_strong_scaling_ladder_plans():
+    """`--ladder strong`: V = 64^4 in total at every N, whole tmp, `scaling` = strong."""
+    import json
+    for n, grid in ((1, [1, 1, 1, 1]), (4, [1, 1, 2, 2])):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--ladder", "strong", "--plan-only"], env=_clean_env(),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["config"]["global_dims"] == [64] * 4 and d["config"]["process_grid"] == grid and d["scaling"] == "strong"
+        assert d["capacity_ring_slices"] == 0 and not d["config"]["headline_ladder"] and len(d["config"]["memory_ladder"]) == 1
+
+
 def test_half_volume_ladder_plans_eight_ranks():
     """`python bench.py --gpus 8 --half --plan-only`: the declared half-volume ladder -- 128^4 as two half solves per GPU
     share of 128 x 64 x 32 x 128 sites on a (1,2,4,1) grid (x0, which half fields are compact in, and x3, swept in chunks

@@ -48,3 +48,29 @@ def test_async_register_check(tmp_path):
     assert r.returncode == 1 and "touched in between: 1" in r.stdout
     # no hand-waited groups at all is an error too (not a PIPE build)
     assert _run("check_async_regs.py", _kernel("\ts_mov_b32 s0, s1\n"), tmp_path).returncode == 1
+
+
+def test_async_register_check_fails_on_a_loop_without_a_retire(tmp_path):
+    """A path that comes round to the next issue (or leaves the kernel) without passing a retiring wait: the loads of the
+    step before are still in flight when their registers are re-issued.  Tolerated only as the two statically infeasible
+    paths of the groups n1 / n2 (the walker is not path-sensitive, tools/check_async_regs.py); one of group p, or a second
+    one of n1, fails the build."""
+    def step(tag, reg):
+        return (f"\t; ASYNC_ISSUE {tag}\n\tglobal_load_dwordx4 v[{reg}:{reg + 3}], v[2:3], off\n\t; ASYNC_ISSUED {tag}\n")
+    retire = lambda tag: f"\t;;#ASMSTART\n\ts_waitcnt vmcnt(3) ; ASYNC_RETIRE {tag}\n\t;;#ASMEND\n"  # noqa: E731
+    # group p in a loop whose back edge skips the retire
+    loop_p = _kernel(".LBB0_1:\n" + step("p", 8) + "\ts_cbranch_scc1 .LBB0_1\n" + retire("p"))
+    r = _run("check_async_regs.py", loop_p, tmp_path)
+    assert r.returncode == 1 and "NOT on the allow-list" in r.stdout and "reached the next issue" in r.stdout
+    # the same shape for n1 is the tolerated infeasible path ...
+    loop_n1 = _kernel(".LBB0_1:\n" + step("n1", 8) + "\ts_cbranch_scc1 .LBB0_1\n" + retire("n1"))
+    assert _run("check_async_regs.py", loop_n1, tmp_path).returncode == 0
+    # ... but two back edges without a retire are one too many
+    loop_n1_twice = _kernel(".LBB0_1:\n" + step("n1", 8) + "\ts_cbranch_scc1 .LBB0_1\n\ts_cbranch_vccz .LBB0_2\n" + retire("n1")
+                            + "\ts_branch .LBB0_3\n.LBB0_2:\n\ts_nop 0\n.LBB0_4:\n" + step("n1", 8) + retire("n1") + ".LBB0_3:\n")
+    r = _run("check_async_regs.py", loop_n1_twice, tmp_path)
+    assert r.returncode == 1 and "NOT on the allow-list" in r.stdout
+    # a path that runs off the end of the kernel with group p in flight
+    off_end = _kernel(step("p", 8) + "\ts_cbranch_scc1 .LBB0_9\n" + retire("p") + ".LBB0_9:\n\ts_nop 0\n")
+    r = _run("check_async_regs.py", off_end, tmp_path)
+    assert r.returncode == 1 and "ran off the end" in r.stdout

@@ -280,6 +280,44 @@ def test_bare_bench_command_half_volume_option():
     assert "halo_exchange" not in comm  # every exchange of the timed region in the split form
 
 
+@pytest.mark.parametrize("how", ["begin_fails_on_one_rank", "free_memory_too_small"])
+def test_bare_bench_command_steps_down_the_memory_ladder(how):
+    """`python bench.py --gpus 4 --step-down` with less memory than the first rungs need (BCG_DEBUG_FIELD_BUDGET, the
+    library's stand-in for a full device), native transport over the stand-in, ranks sharing GPU 0.
+    begin_fails_on_one_rank: ONLY rank 2 is short and the free-memory check is told to trust what it reads, so it is
+    bcg_sbcgrq_begin that finds out, on one rank -- the ranks must agree before their first collective (no rank left waiting
+    in thinQR's all-reduce), every rank abandons ring 16, then ring 8, and the half-volume form runs in the same processes.
+    free_memory_too_small: every rank reads too little free memory: the ring rungs are skipped without allocating."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32",
+               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500", BCG_HALF_CHUNK="4", BCG_BENCH_RESERVE=str(8 << 20))
+    field = 32 * 8 * 8 * 16 * 768  # one full field at m = 16: 25.2 MB; a ring rung holds 10 of them, the half-volume form 11 halves
+    if how == "begin_fails_on_one_rank":
+        env.update(BCG_DEBUG_FIELD_BUDGET=str(int(7.5 * field)), BCG_DEBUG_BUDGET_ONLY_RANK="2", BCG_BENCH_TRUST_FREE="1")
+    else:
+        env.update(BCG_DEBUG_FIELD_BUDGET=str(int(12.0 * field)))  # plans incl. links, faces, scratch: 14.3, 13.8 and 9.7 fields
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1",
+           "--local-dims", "32", "8", "8", "16", "--capacity", "16", "--step-down"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    _sweep_mock_files()
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    notes = d["config"]["memory_ladder"]
+    assert [n["rung"] for n in notes] == ["ring 16", "ring 8", "half-volume"] and notes[-1]["verdict"] == "ran"
+    want = "abandoned" if how == "begin_fails_on_one_rank" else "skipped"
+    assert all(n["verdict"].startswith(want) for n in notes[:2]), notes
+    assert d["config"]["memory_ladder_rung"] == "half-volume" and d["config"]["half_volume_solves"] and d["capacity_ring_slices"] == 0
+    assert "NOT asked for by a flag" in d["config"]["workload"] and d["config"]["global_dims"] == [32, 16, 16, 16]
+    assert d["n_gpus"] == 4 and d["steps"] == 4 and d["value"] > 0 and d["residual_after_timed_steps"] < 1.0
+    assert "memory ladder: running half-volume" in out.stderr
+    if how == "begin_fails_on_one_rank":
+        assert "another rank of the process grid could not allocate" in out.stderr  # what ranks 0, 1, 3 were told
+        assert "rank 2: BCG_ERR_HIP" in out.stderr                                    # ... and rank 2 itself
+
+
 NATIVE_CASES = [
     # dims,             grid,          m,  ring, overlap (split exchange: second stream + events), blocks
     ([32, 4, 4, 8], [1, 1, 1, 2], 16, 0, True, "8"),     # x3 split over two ranks: + and - neighbour are the same peer

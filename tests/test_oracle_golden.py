@@ -145,3 +145,22 @@ def test_shift_retirement_against_live_reference(orc):
     visited = got["trace"]["residual_shift"] >= 0
     assert visited[0, 1:].all() and not visited[-1, 1:].all()   # all shifts start active, some retire before the end
     assert rel_err(orc.true_residuals(U, [V], mass, B, shifts, got["X"]), R.true_residuals(B, shifts, ref["X"])) < 1e-6
+
+
+def test_nd_operator_against_the_reference_1d_operator_line_by_line(orc):
+    """The one place oracle and product could share a mistake is the n-D operator (the reference has none).  An evaluation
+    that does not share the repository's formula: the reference's 1-D loop (inc/dirac_op.hpp:17-20), written in numpy and
+    pinned HERE against the reference's own fixture, applied along every lattice line of every direction with the
+    staggered sign (conftest.hop_by_lines).  The oracle's n-D D and A must agree with it."""
+    from conftest import hop_by_lines, reference_D_line
+    g = np.load(golden_files("ref1d_v128_m3.npz")[0])
+    mass = float(g["mass"])
+    D1 = lambda x: reference_D_line(g["U"][:, 0], x)  # noqa: E731
+    assert rel_err(mass * mass * g["B"] - D1(D1(g["B"])), g["op_B"]) < TOL_KERNEL  # the numpy line operator IS the reference's
+    for dims, m in (([6, 4, 4, 2], 3), ([4, 2, 6], 2), ([3, 5], 4), ([4, 4, 2, 6], 8)):
+        V = int(np.prod(dims))
+        U = orc.fill_gauge(dims, 77)
+        psi = orc.fill_field(m, V, 78)
+        want = hop_by_lines(U, dims, psi)
+        assert rel_err(orc.hop(U, dims, psi), want) < TOL_KERNEL, dims
+        assert rel_err(orc.dirac_apply(U, dims, 0.3, psi), 0.09 * psi - hop_by_lines(U, dims, want)) < TOL_KERNEL, dims

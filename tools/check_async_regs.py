@@ -9,6 +9,13 @@ and this script walks the device assembly of every k_hop4b instantiation from IS
 branches are followed, conditional ones fork) to the RETIRE marker or to a hand-written end-of-step wait (vmcnt(3) or
 less): no instruction on any such path may name a destination register of the group, and every path must end in one.
 
+Paths that leave a step without a retire ("lost") FAIL the check, with one allow-list: the walker is not path-sensitive, and
+the groups n1 / n2 (the next step's outer rows) are issued under `more` while the loop's exit and the last step's waits sit
+under `!more`, so for each of them exactly two statically infeasible paths exist -- one that comes round to the next issue
+through the `!more` side of the step's tail, one that leaves the loop behind the issue and runs to s_endpgm.  Those two
+(at most one of each kind, groups n1 and n2 only) are reported and tolerated; any further lost path, a lost path of another
+group, or a jump table fails the build (tests/test_build_checks.py feeds a synthetic loop-without-retire listing).
+
 usage: tools/check_async_regs.py <device asm from `hipcc -S --cuda-device-only`>   exit status 1 on a violation
 """
 import re
@@ -87,13 +94,17 @@ def main(path):
                     k += 1
             # statically infeasible paths (the issue sits under `more`, some waits under `!more`) may wander past the loop: they are
             # walked and checked like the others; what must hold is that NO walked instruction touches the registers
-            good = reached > 0 and not bad and regs
+            kinds = {'next issue': sum('reached the next issue' in w for w in why), 'off the end': sum('ran off the end' in w for w in why),
+                     'jump table': sum('jump table' in w for w in why)}
+            allowed = 1 if tag in ('n1', 'n2') else 0
+            lost_ok = kinds['jump table'] == 0 and kinds['next issue'] <= allowed and kinds['off the end'] <= allowed
+            good = reached > 0 and not bad and regs and lost_ok
             print(m.group(1)[28:62], f'group {tag}: {len(regs)} registers ({"AGPRs" if min(regs) >= 1000 else "VGPRs"} from {min(regs) % 1000}), {walked} instructions walked, paths to the retire:',
                   reached, 'lost:', lost, 'touched in between:', len(bad))
             for b_ in bad[:6]:
                 print('     ', b_)
             for w_ in why:
-                print('      (path left the step without a retire marker:', w_ + ')')
+                print('      (path left the step without a retire marker:', w_ + (')' if lost_ok else ') -- NOT on the allow-list: FAIL'))
             ok = ok and bool(good)
     if seen == 0:
         print('no hand-waited load groups found (not a PIPE build?)')
