@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from ._lib import c_dbl_p
 
-SUPPORTED_WIDTHS = (1, 2, 3, 4, 6, 8, 12, 16, 32)
+SUPPORTED_WIDTHS = tuple(range(1, 33))  # the reference's N_rhs is any int (inc/fields.hpp:19-26)
 
 _STATUS = {1: "BCG_ERR_INVALID", 2: "BCG_ERR_UNSUPPORTED", 3: "BCG_ERR_HIP", 4: "BCG_ERR_NO_DEVICE", 5: "BCG_ERR_COMM",
            6: "BCG_ERR_NUMERIC"}

@@ -1616,7 +1616,7 @@ int bcg_sbcgrq_device_bytes_half(const bcg_context* c, int m, int n_shifts, int 
 namespace {
 // parity -1: all local sites; 0 / 1: the parity-compact half (kernels_generic.hip, "Half-volume fields")
 int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
-  if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width not instantiated (supported: 1,2,3,4,6,8,12,16,32)");
+  if (!bcg::width_supported(m)) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "block width out of range (supported: 1 <= m <= 32)");
   if (parity >= 0) {
     if (c->distributed && c->ndim < 2) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields on a lattice divided over ranks: two dimensions or more");
     for (int mu = 0; mu < c->ndim; ++mu)

@@ -1,5 +1,5 @@
-// Generic (any supported block width) HIP kernels for gfx950: the complete hot path in plain VALU
-// form.  They are the product path for widths without an MFMA fast path (m = 1,2,3,4,6,12) and the
+// Generic (any block width 1 <= m <= 32) HIP kernels for gfx950: the complete hot path in plain VALU
+// form.  They are the product path for widths without an MFMA fast path (every m but 8, 16, 32) and the
 // cross-check for the MFMA kernels (kernels_mfma.hip, kernels_stencil.hip) at m = 8,16,32.
 //
 // One thread per OUTPUT complex element everywhere, so global loads/stores are 16 B per lane and
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(256) k_gram_generic(int64_t rows, const double
                                                       const double2* __restrict__ b,
                                                       double2* __restrict__ partials) {
   constexpr int P = M * M;
-  constexpr int TR = (M >= 32) ? 32 : (P < 64 ? 256 : 64);
+  constexpr int TR = (M > 16) ? 32 : (P < 64 ? 256 : 64);  // two tiles of TR rows in LDS: 32 KB at m = 32
   constexpr int NG = (P >= 256) ? 1 : 256 / P;       // row groups
   constexpr int NPT = (P + 255) / 256;               // pairs per thread when P > 256
   __shared__ double2 as[TR * M];
@@ -670,23 +670,43 @@ inline int grid_for(int64_t n, int block, int cap) {
 
 }  // namespace
 
-bool width_supported(int m) {
-  switch (m) {
-    case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 32: return true;
-    default: return false;
-  }
-}
+// Any block width 1 <= m <= 32 (the reference's N_rhs is an arbitrary template int, inc/fields.hpp:19-26): every generic
+// kernel is instantiated for each of them; the MFMA row kernels and the specialised stencil exist at 8, 16 and 32.
+bool width_supported(int m) { return m >= 1 && m <= 32; }
 
 #define BCG_DISPATCH_M(m, CALL)                          \
   switch (m) {                                           \
-    case 1: { constexpr int M = 1; CALL; } break;        \
-    case 2: { constexpr int M = 2; CALL; } break;        \
-    case 3: { constexpr int M = 3; CALL; } break;        \
-    case 4: { constexpr int M = 4; CALL; } break;        \
-    case 6: { constexpr int M = 6; CALL; } break;        \
-    case 8: { constexpr int M = 8; CALL; } break;        \
+    case 1: { constexpr int M = 1; CALL; } break;       \
+    case 2: { constexpr int M = 2; CALL; } break;       \
+    case 3: { constexpr int M = 3; CALL; } break;       \
+    case 4: { constexpr int M = 4; CALL; } break;       \
+    case 5: { constexpr int M = 5; CALL; } break;       \
+    case 6: { constexpr int M = 6; CALL; } break;       \
+    case 7: { constexpr int M = 7; CALL; } break;       \
+    case 8: { constexpr int M = 8; CALL; } break;       \
+    case 9: { constexpr int M = 9; CALL; } break;       \
+    case 10: { constexpr int M = 10; CALL; } break;      \
+    case 11: { constexpr int M = 11; CALL; } break;      \
     case 12: { constexpr int M = 12; CALL; } break;      \
+    case 13: { constexpr int M = 13; CALL; } break;      \
+    case 14: { constexpr int M = 14; CALL; } break;      \
+    case 15: { constexpr int M = 15; CALL; } break;      \
     case 16: { constexpr int M = 16; CALL; } break;      \
+    case 17: { constexpr int M = 17; CALL; } break;      \
+    case 18: { constexpr int M = 18; CALL; } break;      \
+    case 19: { constexpr int M = 19; CALL; } break;      \
+    case 20: { constexpr int M = 20; CALL; } break;      \
+    case 21: { constexpr int M = 21; CALL; } break;      \
+    case 22: { constexpr int M = 22; CALL; } break;      \
+    case 23: { constexpr int M = 23; CALL; } break;      \
+    case 24: { constexpr int M = 24; CALL; } break;      \
+    case 25: { constexpr int M = 25; CALL; } break;      \
+    case 26: { constexpr int M = 26; CALL; } break;      \
+    case 27: { constexpr int M = 27; CALL; } break;      \
+    case 28: { constexpr int M = 28; CALL; } break;      \
+    case 29: { constexpr int M = 29; CALL; } break;      \
+    case 30: { constexpr int M = 30; CALL; } break;      \
+    case 31: { constexpr int M = 31; CALL; } break;      \
     case 32: { constexpr int M = 32; CALL; } break;      \
     default: break;                                      \
   }

@@ -19,8 +19,9 @@
  *    Device layouts are private to the library: fields are [site][colour][rhs] so that
  *    one (site, colour) row of m complex numbers is contiguous.
  *  - Site counts and byte offsets are 64-bit: 128^4 sites fit in int, 128^4 * 768 B does not.
- *  - Block width m (the reference's template parameter N_rhs) is a run-time argument; supported
- *    widths: 1, 2, 3, 4, 6, 8, 12, 16, 32 (BCG_ERR_UNSUPPORTED otherwise).
+ *  - Block width m (the reference's template parameter N_rhs, an arbitrary int: inc/fields.hpp:19-26) is a run-time
+ *    argument: any 1 <= m <= 32 (BCG_ERR_UNSUPPORTED otherwise).  m = 8, 16, 32 run the MFMA row kernels and the
+ *    specialised stencil; every other width the generic kernels (one thread per output element, LDS-staged operands).
  *  - Lattice: up to 4 dimensions, lexicographic site order with x0 fastest, periodic.  ndim = 1,
  *    dims = {V} is exactly the reference's 1-D operator (inc/dirac_op.hpp:14-21); the n-D operator
  *    is  (D psi)(x) = 1/2 sum_mu eta_mu(x) [U_mu(x) psi(x+mu) - U_mu(x-mu)^dagger psi(x-mu)],

@@ -24,8 +24,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_dbl_p = ctypes.POINTER(ctypes.c_double)
 
-SUPPORTED_M = (1, 2, 3, 4, 6, 8, 12, 16, 32)
-REF_SUPPORTED_M = (1, 2, 3, 4, 6, 8, 12, 16, 32)
+SUPPORTED_M = tuple(range(1, 33))
+REF_SUPPORTED_M = (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 32)
 
 
 def build(ref=None):

@@ -38,14 +38,37 @@ Gauge load_gauge(int ndim, const int* dims, const double* U) {
 
 #define ORC_DISPATCH(m, CALL)          \
   switch (m) {                         \
-    case 1: { constexpr int M = 1; CALL; } break;   \
-    case 2: { constexpr int M = 2; CALL; } break;   \
-    case 3: { constexpr int M = 3; CALL; } break;   \
-    case 4: { constexpr int M = 4; CALL; } break;   \
-    case 6: { constexpr int M = 6; CALL; } break;   \
-    case 8: { constexpr int M = 8; CALL; } break;   \
+    case 1: { constexpr int M = 1; CALL; } break; \
+    case 2: { constexpr int M = 2; CALL; } break; \
+    case 3: { constexpr int M = 3; CALL; } break; \
+    case 4: { constexpr int M = 4; CALL; } break; \
+    case 5: { constexpr int M = 5; CALL; } break; \
+    case 6: { constexpr int M = 6; CALL; } break; \
+    case 7: { constexpr int M = 7; CALL; } break; \
+    case 8: { constexpr int M = 8; CALL; } break; \
+    case 9: { constexpr int M = 9; CALL; } break; \
+    case 10: { constexpr int M = 10; CALL; } break; \
+    case 11: { constexpr int M = 11; CALL; } break; \
     case 12: { constexpr int M = 12; CALL; } break; \
+    case 13: { constexpr int M = 13; CALL; } break; \
+    case 14: { constexpr int M = 14; CALL; } break; \
+    case 15: { constexpr int M = 15; CALL; } break; \
     case 16: { constexpr int M = 16; CALL; } break; \
+    case 17: { constexpr int M = 17; CALL; } break; \
+    case 18: { constexpr int M = 18; CALL; } break; \
+    case 19: { constexpr int M = 19; CALL; } break; \
+    case 20: { constexpr int M = 20; CALL; } break; \
+    case 21: { constexpr int M = 21; CALL; } break; \
+    case 22: { constexpr int M = 22; CALL; } break; \
+    case 23: { constexpr int M = 23; CALL; } break; \
+    case 24: { constexpr int M = 24; CALL; } break; \
+    case 25: { constexpr int M = 25; CALL; } break; \
+    case 26: { constexpr int M = 26; CALL; } break; \
+    case 27: { constexpr int M = 27; CALL; } break; \
+    case 28: { constexpr int M = 28; CALL; } break; \
+    case 29: { constexpr int M = 29; CALL; } break; \
+    case 30: { constexpr int M = 30; CALL; } break; \
+    case 31: { constexpr int M = 31; CALL; } break; \
     case 32: { constexpr int M = 32; CALL; } break; \
     default: return -1;                \
   }

@@ -114,14 +114,17 @@ void store_mat(const block_matrix<N>& m, double* p) {
   std::memcpy(p, m.data(), sizeof(cd) * N * N);
 }
 
+// (every width instantiates the reference's templates over Eigen fixed-size matrices: the widths with fixtures only)
 #define REF_DISPATCH(m, CALL)                      \
   switch (m) {                                     \
-    case 1: { constexpr int N = 1; CALL; } break;  \
-    case 2: { constexpr int N = 2; CALL; } break;  \
-    case 3: { constexpr int N = 3; CALL; } break;  \
-    case 4: { constexpr int N = 4; CALL; } break;  \
-    case 6: { constexpr int N = 6; CALL; } break;  \
-    case 8: { constexpr int N = 8; CALL; } break;  \
+    case 1: { constexpr int N = 1; CALL; } break; \
+    case 2: { constexpr int N = 2; CALL; } break; \
+    case 3: { constexpr int N = 3; CALL; } break; \
+    case 4: { constexpr int N = 4; CALL; } break; \
+    case 5: { constexpr int N = 5; CALL; } break; \
+    case 6: { constexpr int N = 6; CALL; } break; \
+    case 7: { constexpr int N = 7; CALL; } break; \
+    case 8: { constexpr int N = 8; CALL; } break; \
     case 12: { constexpr int N = 12; CALL; } break; \
     case 16: { constexpr int N = 16; CALL; } break; \
     case 32: { constexpr int N = 32; CALL; } break; \

@@ -21,6 +21,8 @@ Files written (numpy .npz, complex128 in the reference's host layout, see oracle
   ref1d_v128_other_solvers.npz  CG, SCG (N_rhs = 1), BCG, BCGrQ (N_rhs = 3) at the reference's test configuration.
   ref4d_8x8x8x8_m4.npz inputs from the oracle's counter-based generator (seeds stored), summary of
                        the reference solve only (iterations, residuals, column norms of X).
+  ref1d_v96_m5.npz ref4d_4x2x4x2_m7.npz   odd block widths (the reference's N_rhs is any int), full data.
+`generate.py NAME.npz ...` writes the named fixtures only.
 """
 import os
 import sys
@@ -68,7 +70,12 @@ def solve(R, B, shifts, eps, eps_shifts, early=0):
     return d
 
 
+ONLY = set(sys.argv[1:])  # `generate.py NAME.npz ...`: write the named fixtures only (the others stay as committed)
+
+
 def gen_1d(name, V, m, mass, shifts, eps, eps_shifts, seed, early, with_primitives=True):
+    if ONLY and name not in ONLY:
+        return
     R = oracle.Reference(four_d=False)
     U = R.make_dirac_1d(V, mass, seed)  # srand(seed); dirac_op D(V, mass);  rand() state continues into B
     B = R.field_random(m, V)
@@ -82,6 +89,8 @@ def gen_1d(name, V, m, mass, shifts, eps, eps_shifts, seed, early, with_primitiv
 
 
 def gen_nd(name, dims, m, mass, shifts, eps, eps_shifts, seed, early, full=True):
+    if ONLY and name not in ONLY:
+        return
     O = oracle.Oracle()
     R = oracle.Reference(four_d=True)
     V = int(np.prod(dims))
@@ -109,6 +118,8 @@ def gen_nd(name, dims, m, mass, shifts, eps, eps_shifts, seed, early, full=True)
 
 def gen_other_solvers(name):
     """CG, SCG, BCG, BCGrQ of the unmodified reference at its own test configuration (test/solvers.cpp:8-91)."""
+    if ONLY and name not in ONLY:
+        return
     V, mass, eps = 128, 0.5, 1e-10
     shifts = [0.0, 0.01, 0.10, 0.20, 0.9]
     R = oracle.Reference(four_d=False)
@@ -143,6 +154,9 @@ def main():
     gen_nd("ref4d_4x2x2x4_m32.npz", [4, 2, 2, 4], 32, 0.3, s8, 1e-10, 1e-12, 15, early=1)
     gen_1d("ref1d_v64_m6.npz", 64, 6, 0.4, [0.0, 0.05], 1e-10, 1e-15, 2, early=2)
     gen_other_solvers("ref1d_v128_other_solvers.npz")
+    # odd block widths: the reference's N_rhs is an arbitrary template int (inc/fields.hpp:19-26)
+    gen_1d("ref1d_v96_m5.npz", 96, 5, 0.3, [0.0, 0.02, 0.5], 1e-10, 1e-15, 3, early=2)
+    gen_nd("ref4d_4x2x4x2_m7.npz", [4, 2, 4, 2], 7, 0.15, s4, 1e-10, 1e-12, 16, early=2)
 
 
 if __name__ == "__main__":

@@ -121,6 +121,52 @@ def _report(line):
         pass
 
 
+@pytest.mark.parametrize("m", [5, 7, 9, 10, 11, 13, 14, 15, 17, 19, 20, 23, 24, 27, 29, 31])
+def test_every_block_width(bc, orc, m):
+    """The reference's N_rhs is an arbitrary template int (inc/fields.hpp:19-26): every 1 <= m <= 32 exists here (generic
+    kernels outside 8, 16, 32).  Per width: every field primitive and the operator against the oracle (pinned to the
+    reference at m = 5 and 7 by the fixtures ref1d_v96_m5 / ref4d_4x2x4x2_m7, which the fixture tests above run on the
+    GPU too), then four fixed iterations of SBCGrQ, X and every coefficient."""
+    dims, mass, shifts = [6, 4, 2, 3], 0.2, [0.0, 1e-3, 0.5]
+    ctx = bc.Context(dims)
+    V = ctx.V
+    D = bc.dirac_op(ctx, mass, seed=5)
+    U = orc.fill_gauge(dims, 5)
+    Bh, Yh = orc.fill_field(m, V, 6), orc.fill_field(m, V, 7)
+    rng = np.random.default_rng(m)
+    M = rng.uniform(-1, 1, (m, m)) + 1j * rng.uniform(-1, 1, (m, m))
+    F = lambda a: bc.block_fermion_field(ctx, m, a)  # noqa: E731
+    assert np.array_equal(F(Bh).download(), Bh)
+    out = bc.block_fermion_field(ctx, m)
+    D.op(out, F(Bh))
+    assert rel_err(out.download(), orc.dirac_apply(U, dims, mass, Bh)) < TOL_KERNEL
+    D.D(out, F(Bh))
+    assert rel_err(out.download(), orc.hop(U, dims, Bh)) < TOL_KERNEL
+    assert rel_err(F(Yh).add(F(Bh), 0.3).download(), orc.add_scalar(Yh, Bh, 0.3)) < TOL_KERNEL
+    assert rel_err(F(Yh).add(F(Bh), M).download(), orc.add_matrix(Yh, Bh, M)) < TOL_KERNEL
+    assert rel_err(F(Yh).rescale_add(M, F(Bh), 1.0).download(), orc.rescale_add_matrix(Yh, M, Bh, 1.0)) < TOL_KERNEL
+    assert rel_err(F(Yh).hermitian_dot(F(Bh)), orc.hermitian_dot(Yh, Bh)) < TOL_KERNEL
+    q = F(Yh)
+    R = q.thinQR()
+    qo, Ro = orc.thin_qr(Yh)
+    assert rel_err(R, Ro) < TOL_KERNEL and rel_err(q.download(), qo) < 1e-12
+    assert rel_err(F(Bh).multiply_upper_triangular_inverse_RHS(Ro).download(), orc.tri_solve_rhs(Bh, Ro)) < 1e-12
+    X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+    info = bc.SBCGrQ(X, F(Bh), D, shifts, 0.0, 0.0, max_iterations=4, trace_limit=4, return_info=True)
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=4, trace_limit=4)
+    assert info["iterations"] == 4 and rel_err(np.stack([x.download() for x in X]), o["X"]) < 1e-11
+    for key in ("alpha", "rho", "delta", "alpha_s", "beta_s"):
+        assert rel_err(info["trace"][key], o["trace"][key]) < TOL_COEFF, key
+
+
+def test_odd_block_width_beyond_the_range_is_refused(bc):
+    ctx = bc.Context([8])
+    for m in (0, 33, 64):
+        with pytest.raises(bc.BlockCGError) as e:
+            bc.block_fermion_field(ctx, m)
+        assert e.value.code == 2  # BCG_ERR_UNSUPPORTED
+
+
 def test_config0_solution_against_the_reference(bc, orc):
     """BASELINE config 0 (V = 1000, mass 1e-3, tol 1e-10, m = 4, 1 shift; fixture = the unmodified reference's run): the
     iteration counts side by side and || X_gpu - X_ref || / || X_ref ||, reported and bounded.  The count differs by the
@@ -323,8 +369,8 @@ def test_error_behaviour(bc):
     assert e.value.code == 1
     with pytest.raises(bc.BlockCGError):  # negative shift, :99
         bc.SBCGrQ(X, B, D, [-0.1, 0.0], 1e-10)
-    with pytest.raises(bc.BlockCGError) as e:  # width not instantiated
-        bc.block_fermion_field(ctx, 5)
+    with pytest.raises(bc.BlockCGError) as e:  # width out of range (1 <= m <= 32)
+        bc.block_fermion_field(ctx, 33)
     assert e.value.code == 2
     # CholQR breakdown is reported, not silently NaN (a zero block has a singular Gram matrix)
     Z = bc.block_fermion_field(ctx, 3).setZero()
