@@ -272,7 +272,8 @@ def rung_plan(lib, rung, world, m, S):
         V_local = 1
         for l in ld:
             V_local *= l
-        planned.value -= (2 * S + 3 + max(0, depth - 2)) * (V_local // 2) * 3 * m * 16
+        spare = 1 if depth >= 2 and m in (8, 16) else 0  # the spare P_0 of the deferred X_0 update (outside capacity mode)
+        planned.value -= (2 * S + 3 + max(0, depth - 2) + spare) * (V_local // 2) * 3 * m * 16
     L3 = ld[-1]
     return {"gdims": gdims, "planned": planned.value, "overlapped": overlapped, "chunk": chunk, "depth": depth,
             "chunks": ([min(chunk, L3 - lo) for lo in range(0, L3, chunk)] if chunk else [])}

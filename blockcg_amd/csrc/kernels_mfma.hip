@@ -229,6 +229,61 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
   }
 }
 
+// Phase C of shift 0 with the update of X_0 DEFERRED (SBCGrQ, defer_x0 in blockcg_capi.hip):  q = Q rinv (in registers, not
+// stored);  Pout = P B + q.  X_0 is not touched -- the pass that closes the group of iterations adds the group's updates to
+// it at once (k_phaseC_multi, XACC) -- so this pass moves three fields instead of five.  Pout may be P (in place: a wave
+// reads its tile before it writes it) or another buffer (the first iteration of a group: the group's first P_0 must
+// survive).  The product sequence for P is k_phaseC's (rmul_acc and rmul_acc2 run the same chain per accumulator): the
+// P_0 the operator sees, and with it every coefficient of the iteration, is bit-identical to the undeferred form.
+// mats: [rinv, B].
+template <int M, bool AHEAD>
+__global__ void __launch_bounds__(256) k_phaseC_p0(int64_t rows, const double2* __restrict__ Q, const double2* P, double2* Pout,
+                                                   const double2* __restrict__ mats) {
+  constexpr int NW = 4;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(smem, mats, tid, NW * 64);
+  stage_matrix<M>(smem + MD, mats + static_cast<int64_t>(M) * M, tid, NW * 64);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t ntiles = (rows + 15) / 16;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  Tile<M> q, p;
+  if (AHEAD && tile < ntiles) {  // the next tile's loads are in flight while this one is multiplied
+    tile_load<M>(q, Q, tile * 16 + r, kq, tile * 16 + r < rows);
+    tile_load<M>(p, P, tile * 16 + r, kq, tile * 16 + r < rows);
+  }
+  for (; tile < ntiles; tile += stride) {
+    const int64_t row = tile * 16 + r;
+    const bool ok = BCG_ROW_OK(row, rows);
+    if (!AHEAD) {
+      tile_load<M>(q, Q, row, kq, ok);
+      tile_load<M>(p, P, row, kq, ok);
+    }
+    Tile<M> qn, pn;
+    const int64_t nrow = (tile + stride) * 16 + r;
+    if (AHEAD && tile + stride < ntiles) {
+      tile_load<M>(qn, Q, nrow, kq, nrow < rows);
+      tile_load<M>(pn, P, nrow, kq, nrow < rows);
+    }
+    Acc<M> A;
+    acc_zero<M>(A);
+    rmul_acc<M>(A, q, smem, lane);
+    tile_from_acc<M>(q, A);
+    Acc<M> AP;
+    acc_from_tile<M>(AP, q);
+    rmul_acc<M>(AP, p, smem + MD, lane);
+    tile_from_acc<M>(p, AP);
+    tile_store<M>(p, Pout, row, kq, ok);
+    if (AHEAD && tile + stride < ntiles) {
+      q = qn;
+      p = pn;
+    }
+  }
+}
+
 // Phase C of NS = 2 .. 4 consecutive iterations in one pass over the fields of the shifted systems (m = 8, 16).
 // Only P_0 feeds the operator, so the updates of the shifts s >= 1 of an iteration can wait for a later one as long as
 // that iteration's un-normalised residual block is kept (phase B of the following iteration then writes its result to
@@ -246,6 +301,11 @@ struct MultiQ {
 };
 struct MultiSteps {
   int first[8], last[8];
+  // XACC (deferred X_0, entry 0 only): before its steps, X_0 += P1 C_0 + q_0 C_1 + ... + q_{xacc-2} C_{xacc-1} -- the X_0 updates of
+  // the group's earlier iterations, composed on the host onto the group's first P_0 (`p1`) and the normalised residual
+  // blocks the kernel holds anyway.  xacc = number of those matrices (0: off); they follow entry 0's step matrices.
+  int xacc;
+  const double2* p1;
 };
 // Blocks: one per CU whatever the matrices take of its LDS.  m = 16: 8 waves, 2 per SIMD -- NS residual tiles, the
 // entry's and the next entry's P and X tiles, two accumulators and the LDS operands in flight are 180 .. 250 registers
@@ -288,6 +348,18 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       }
     }
     const double* mat = smem + (NORM ? NS : 0) * MD;
+    if (NORM && steps.xacc > 0) {  // wave-uniform: the deferred X_0 updates of the group's earlier iterations
+      Tile<M> p1;
+      tile_load<M>(p1, steps.p1, row, kq, ok);
+      const double* cm = mat + 2 * (steps.last[0] - steps.first[0]) * MD;
+      Acc<M> AX;
+      acc_from_tile<M>(AX, x);
+      rmul_acc<M>(AX, p1, cm, lane);
+#pragma unroll
+      for (int j = 0; j + 1 < NS; ++j)
+        if (j + 1 < steps.xacc) rmul_acc<M>(AX, q[j], cm + (j + 1) * MD, lane);
+      tile_from_acc<M>(x, AX);
+    }
     for (int e = 0; e < nent; ++e) {
       Tile<M> pn, xn;
       if (PRE && e + 1 < nent) {  // the next entry's tiles are in flight while this one is multiplied
@@ -295,6 +367,7 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
         tile_load<M>(xn, sp.X[e + 1], row, kq, ok);
       }
       const int first = steps.first[e], last = steps.last[e];  // wave-uniform
+      if (NORM && e == 1 && steps.xacc > 0) mat += steps.xacc * MD;  // entry 0's composed matrices sit behind its step matrices
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         if (j >= first && j < last) {
@@ -532,6 +605,25 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
   }
 }
 
+void launch_phaseC_p0(hipStream_t s, int m, int64_t rows, const double2* Q, const double2* P, double2* Pout, const double2* mats,
+                      int max_blocks) {
+  // Defaults from profiles/r05_phaseC_p0.txt (64^4, m = 16): the next tile's loads in flight during the products and two
+  // blocks per CU, 7.26 ms per launch; without the prefetch 7.56-7.63 ms at 1024, 1536 or 2048 blocks, with it at 1024 blocks
+  // 7.84.  BCG_P0_AHEAD / BCG_P0_BLOCKS: the knobs of that experiment.
+  static const int ahead = std::getenv("BCG_P0_AHEAD") ? std::atoi(std::getenv("BCG_P0_AHEAD")) : 1;
+  static const int blocks = std::getenv("BCG_P0_BLOCKS") ? std::atoi(std::getenv("BCG_P0_BLOCKS")) : 512;
+  const int grid = grid_tiles((rows + 15) / 16, 4, blocks > 0 && blocks < max_blocks ? blocks : max_blocks);
+  if (m == 8) {
+    const size_t lds = sizeof(double) * ((MatLds<8>::DOUBLES + 1) & ~1) * 2;
+    if (ahead) hipLaunchKernelGGL((k_phaseC_p0<8, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+    else hipLaunchKernelGGL((k_phaseC_p0<8, false>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+  } else {
+    const size_t lds = sizeof(double) * ((MatLds<16>::DOUBLES + 1) & ~1) * 2;
+    if (ahead) hipLaunchKernelGGL((k_phaseC_p0<16, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+    else hipLaunchKernelGGL((k_phaseC_p0<16, false>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+  }
+}
+
 int phaseC_multi_matrices(int nsteps, int nent, const int* first, const int* last, bool normalise) {
   int n = normalise ? nsteps : 0;
   for (int e = 0; e < nent; ++e) n += 2 * (last[e] - first[e]);
@@ -545,16 +637,11 @@ bool phaseC_multi_fits(int m, int nsteps, int n_shifts) {
   if (m == 32) return nsteps == 2;  // un-normalised blocks are not kept at m = 32
   return m == 8 || m == 16;         // more shifts than one launch has LDS room for: several launches (phaseC_multi_max_entries)
 }
-int phaseC_multi_max_entries(int m, int nsteps, bool normalise) {
-  const int per_entry = 2 * nsteps;
-  const int room = static_cast<int>(150 * 1024 / mat_lds_bytes(m)) - (normalise ? nsteps : 0);
-  const int n = room / per_entry;
-  return n > 8 ? 8 : n;
-}
+int phaseC_multi_capacity(int m) { return static_cast<int>(150 * 1024 / mat_lds_bytes(m)); }
 
 void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
                          double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks,
-                         bool normalise) {
+                         bool normalise, int xacc, const double2* p1) {
   ShiftPtrs sp{};
   MultiSteps st{};
   MultiQ qs{};
@@ -565,7 +652,9 @@ void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const d
     st.last[k] = last[k];
   }
   for (int j = 0; j < 4; ++j) qs.q[j] = Q[j < nsteps ? j : nsteps - 1];
-  const int nmat = phaseC_multi_matrices(nsteps, nent, first, last, normalise);
+  st.xacc = (normalise && nent > 0) ? xacc : 0;
+  st.p1 = p1;
+  const int nmat = phaseC_multi_matrices(nsteps, nent, first, last, normalise) + st.xacc;
   const int cus = max_blocks / 4 > 0 ? max_blocks / 4 : 1;  // one block per CU
 #define BCG_MULTI(MM, NW, NS, NORM, PRE)                                                                           \
   {                                                                                                                \

@@ -32,10 +32,17 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
 // residual block of step j -- un-normalised with normalise = true (m = 8, 16: mats starts with rinv_0 .. rinv_{nsteps-1}),
 // as stored otherwise (m = 32) -- entry e takes the steps first[e] <= j < last[e]; then per entry and step A, B.
 bool phaseC_multi_fits(int m, int nsteps, int n_shifts);  // the grouping is available for this width and depth
-int phaseC_multi_max_entries(int m, int nsteps, bool normalise);  // entries of nsteps steps one launch has LDS room for
+// coefficient matrices one launch has LDS room for (150 KB of a CU's 160): the rinv_j, then per entry its step matrices
+// (and entry 0's composed ones, xacc below); at most 8 entries per launch
+int phaseC_multi_capacity(int m);
+// xacc > 0 (normalise only; deferred update of X_0): before entry 0's steps, X[0] += p1 C_0 + q_0 C_1 + ... + q_{xacc-2} C_{xacc-1},
+// the xacc composed matrices following entry 0's step matrices in `mats`
 void launch_phaseC_multi(hipStream_t s, int m, int64_t rows, int nsteps, const double2* const* Q, double2* const* X,
                          double2* const* P, int nent, const int* first, const int* last, const double2* mats, int max_blocks,
-                         bool normalise = true);
+                         bool normalise = true, int xacc = 0, const double2* p1 = nullptr);
+// Shift 0's phase C with the update of X_0 deferred (m = 8, 16): Pout = P mats[1] + Q mats[0]; mats = [rinv, B]
+void launch_phaseC_p0(hipStream_t s, int m, int64_t rows, const double2* Q, const double2* P, double2* Pout, const double2* mats,
+                      int max_blocks);
 void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const double2* x, const double2* Cd, double b,
                       RmulMode mode, int max_blocks);
 int launch_gram_mfma(hipStream_t s, int m, int64_t rows, const double2* a, const double2* b, double2* partials,
@@ -65,6 +72,8 @@ struct HopTuning {
   int boundary_n = 0;
   bool nontemporal = true;       // stream `out` (and p) past L2 (the only form instantiated)
   GramFold fold;                 // set per launch by the context: fold the fused Gram partials in the kernel (column forms)
+  int super_patch = 0;           // k_hop4b: the eight XCD classes' concurrent patches form a 2 x 2 x 2 super-patch (HopWalk::super;
+                                 // BCG_HOP_SUPER; measured: profiles/r05_stencil_super_patch.txt)
   int blocks_overlap = 512;      // grid of the interior launch while a halo exchange is in flight.  Measured: any grid whose
                                  // per-XCD share differs from the 64 tiles of a patch slice loses the x3 walk (480 blocks: +3 ms),
                                  // so CUs are not vacated for the transport; its kernels co-reside where registers allow

@@ -66,10 +66,33 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst));  // no "memory" clobber: it would force the callers' captured state into scratch;
 }                                            // the block barriers around every use order it against the compiler's LDS accesses
-// The same with the source given as base + per-lane offset.  The scalar-base encoding of this instruction
-// (`global_load_lds_dwordx4 v_off, s[base:base+1]`) was tried to save the 64-bit vector address arithmetic in front of it:
-// the kernel then aborts at its first launch (two runs, with and without an immediate offset), so the address stays a VGPR pair.
+// The same with the source given as base + per-lane offset.  -DBCG_HOP4B_GLDS_SBASE=1: the scalar-base encoding of the
+// instruction (`global_load_lds_dwordx4 v_off, s[base:base+1]`), which saves the 64-bit vector address arithmetic in front
+// of every DMA.  Round 4 tried it and the kernel aborted at its first launch (a memory fault), with and without an immediate
+// offset.  Cause (round 5, from the hazard table the asm guide gives for operands INSIDE an asm string): the "s" operand is
+// materialised by v_readfirstlane where hipcc keeps the wave-uniform pointer in VGPRs, and a VALU write of an SGPR needs
+// five wait states before a vector-memory instruction reads it as its base; hipcc pads hazards only for instructions it
+// emits itself, and the string's two s_mov and one s_nop in front of the load are three.  With `s_nop 4` opening the string
+// the form runs and passes the parity suites (profiles/r05_glds_scalar_base.txt has the A/B).
+#ifndef BCG_HOP4B_GLDS_SBASE
+#define BCG_HOP4B_GLDS_SBASE 0
+#endif
+#if BCG_HOP4B_GLDS_SBASE
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  // (17 of the call sites hold their wave-uniform base in VGPRs: an "s" operand on it does not assemble -- hipcc hands
+  //  the asm a VGPR pair -- so the halves are read into SGPRs here, which is where the hazard comes from)
+  const unsigned long long a = reinterpret_cast<unsigned long long>(sbase);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+  const unsigned long long sb = (static_cast<unsigned long long>(hi) << 32) | lo;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sb), "s"(lds_dst));
+}
+#else
 __device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) { glds16_link(sbase + voff, lds_dst); }
+#endif
 // One row element per lane (16 bytes at sbase + voff + IMM) by a load hipcc does not see: its result counts as available at
 // once, so the CALLER waits (s_waitcnt vmcnt) before the first use.  For values loaded one loop iteration ahead: hipcc's
 // own bookkeeping loses count across the loop's back edge and waits for every load of the NEW iteration at their use.
@@ -273,6 +296,11 @@ struct HopWalk {
   int list_n;
   // k_hop4c / k_hop4b with the fused Gram product: fold the block partials inside the kernel (gram_fold); out = nullptr: off
   GramFold fold;
+  // k_hop4b: the patches the eight XCD classes work on at the same time form a 2 x 2 x 2 SUPER-PATCH (class bit 0 / 1 / 2 =
+  // the patch's position in x0 / x1 / x2 inside it) instead of lying a quarter of the lattice apart: the rows that cross
+  // a face between two of them are then read by two XCDs within a few steps of each other, and the second read can be
+  // served by the memory-side cache (HopTuning::super_patch).  Tile order only: every tile is still visited once.
+  int super;
 };
 
 // Pacing counters are read with the same read-modify-write unit that increments them (an add of 0): the blocks of a
@@ -1167,8 +1195,18 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
   const unsigned per = gridDim.x >> 3;
 
   for (int pk = 0; pk < ppc; ++pk) {
-    const int pi = cls * ppc + pk;
-    const int d4 = pi % r4, d5 = (pi / r4) % r5, d6 = pi / (r4 * r5);
+    int d4, d5, d6;
+    if (hw.super) {  // super-patch pk, this class's corner of it
+      const int h4 = r4 >> 1, h5 = r5 >> 1;
+      d4 = 2 * (pk % h4) + (cls & 1);
+      d5 = 2 * ((pk / h4) % h5) + ((cls >> 1) & 1);
+      d6 = 2 * (pk / (h4 * h5)) + (cls >> 2);
+    } else {
+      const int pi = cls * ppc + pk;
+      d4 = pi % r4;
+      d5 = (pi / r4) % r5;
+      d6 = pi / (r4 * r5);
+    }
     const int x0b = (d4 * r0 + d0) * SPW, x1 = d5 * hw.p1 + d1 * 2 + e1, x2 = d6 * hw.p2 + d2 * 2 + e2;
     const int col = x0b + L0 * (x1 + L1 * x2);  // this wave's first site at x3 = 0
     const int vs0 = pk * win.x3_n - win.x3_lo;  // tile number of slice x3 in this block's sequence: vs0 + x3
@@ -2235,6 +2273,7 @@ static HopPlan plan_hop4(int m, const LatticeDev& lat, int max_blocks, const Hop
                    lat.L[2] % p2 == 0 && pl.ntiles % 8 == 0 && max_blocks % 8 == 0 && pl.ntiles / 8 >= max_blocks / 8;
   pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, nullptr, 0, GramFold{}};  // lexicographic = one patch
   if (ok3) pl.hw = HopWalk{p0, p1, p2, 1, nullptr, 0, 0, 0, nullptr, 0, GramFold{}};
+  if (ok3 && tune.super_patch && (lat.L[0] / p0) % 2 == 0 && (lat.L[1] / p1) % 2 == 0 && (lat.L[2] / p2) % 2 == 0) pl.hw.super = 1;
   if (cls == 2 && tune.boundary_list != nullptr) {  // the boundary class from its tile list, round-robin
     pl.hw = HopWalk{lat.L[0], lat.L[1], lat.L[2], 0, nullptr, 0, 0, 0, tune.boundary_list, tune.boundary_n, GramFold{}};
     pl.grid = tune.boundary_n < max_blocks ? tune.boundary_n : max_blocks;

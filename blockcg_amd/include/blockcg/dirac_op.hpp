@@ -19,40 +19,44 @@ class dirac_op {
     lat_ = &blockcg::lattice::one_dimensional(V_);
     create();
     blockcg::rand_state_guard keep_callers_rand_sequence;
-    blockcg::check(bcg_gauge_upload(g_, reinterpret_cast<const double*>(U.data())), lat_->ctx(), "bcg_gauge_upload");
+    blockcg::check(bcg_gauge_upload(g_.get(), reinterpret_cast<const double*>(U.data())), lat_->ctx(), "bcg_gauge_upload");
   }
   // n-D: links i.i.d. uniform [-1,1) from the counter-based device generator
   dirac_op(blockcg::lattice& lat, double mass_, unsigned long long seed) : V(lat.V()), mass(mass_), lat_(&lat) {
     create();
-    blockcg::check(bcg_gauge_fill_random(g_, seed), lat_->ctx(), "bcg_gauge_fill_random");
+    blockcg::check(bcg_gauge_fill_random(g_.get(), seed), lat_->ctx(), "bcg_gauge_fill_random");
   }
   // n-D: links given by the caller, [site][mu][3x3 column-major]
   dirac_op(blockcg::lattice& lat, double mass_, const std::complex<double>* links) : V(lat.V()), mass(mass_), lat_(&lat) {
     create();
-    blockcg::check(bcg_gauge_upload(g_, reinterpret_cast<const double*>(links)), lat_->ctx(), "bcg_gauge_upload");
+    blockcg::check(bcg_gauge_upload(g_.get(), reinterpret_cast<const double*>(links)), lat_->ctx(), "bcg_gauge_upload");
   }
-  ~dirac_op() { bcg_gauge_destroy(g_); }
-  dirac_op(const dirac_op&) = delete;
-  dirac_op& operator=(const dirac_op&) = delete;
+  // The reference's dirac_op is implicitly copyable (its links are a std::vector, inc/dirac_op.hpp:10-11).  The links are
+  // immutable after construction, so copies here share the device links (the last copy frees them).
+  ~dirac_op() = default;
+  dirac_op(const dirac_op&) = default;
+  dirac_op& operator=(const dirac_op&) = default;
 
   // lhs = (m^2 - D^2) rhs  (:36-43)
   template <int N_rhs>
   void op(block_fermion_field<N_rhs>& lhs, const block_fermion_field<N_rhs>& rhs) const {
     rhs.flush();
-    blockcg::check(bcg_dirac_apply(lat_->ctx(), g_, mass, lhs.handle(), rhs.handle()), lat_->ctx(), "dirac_op::op");
+    blockcg::check(bcg_dirac_apply(lat_->ctx(), g_.get(), mass, lhs.handle(), rhs.handle()), lat_->ctx(), "dirac_op::op");
     lhs.device_written();
   }
 
-  bcg_gauge* handle() const { return g_; }
+  bcg_gauge* handle() const { return g_.get(); }
   blockcg::lattice& lat() const { return *lat_; }
 
  private:
   void create() {
     blockcg::rand_state_guard keep_callers_rand_sequence;
-    blockcg::check(bcg_gauge_create(lat_->ctx(), &g_), lat_->ctx(), "bcg_gauge_create");
+    bcg_gauge* g = nullptr;
+    blockcg::check(bcg_gauge_create(lat_->ctx(), &g), lat_->ctx(), "bcg_gauge_create");
+    g_ = std::shared_ptr<bcg_gauge>(g, [](bcg_gauge* p) { bcg_gauge_destroy(p); });
   }
   blockcg::lattice* lat_;
-  bcg_gauge* g_ = nullptr;
+  std::shared_ptr<bcg_gauge> g_;
 };
 
 #endif

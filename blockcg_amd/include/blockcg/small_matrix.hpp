@@ -101,6 +101,42 @@ struct carray {
 };
 
 template <int Rows, int Cols>
+class cmatrix;
+
+// What A.fullPivLu() returns (Eigen's FullPivLU, complete pivoting): the two members the reference's solver templates use,
+// .solve(B) (inc/block_solvers.hpp:31,36,73,142,166) and .inverse().  Own code; the elimination is the one the library
+// itself runs for alpha and beta_s (csrc/small_matrix.hpp: pivot = the entry of largest modulus of the remaining block,
+// found in column-major order), so a solver written against these headers in the reference's style gets the coefficients
+// the library's own SBCGrQ computes.
+template <int N>
+class full_piv_lu {
+ public:
+  explicit full_piv_lu(const cmatrix<N, N>& A);
+  template <int C>
+  cmatrix<N, C> solve(const cmatrix<N, C>& B) const;
+  cmatrix<N, N> inverse() const;
+
+ private:
+  cplx w_[N * N];  // L (unit diagonal, below) and U (on and above the diagonal) of the row- and column-permuted matrix
+  int rp_[N], cp_[N];
+  cplx& w(int i, int j) { return w_[j * N + i]; }
+  const cplx& w(int i, int j) const { return w_[j * N + i]; }
+};
+
+// What A.llt() returns (Eigen's LLT): .matrixL() is the lower-triangular Cholesky factor, A = L L^dagger, and the
+// reference takes .matrixL().adjoint() as the R of thinQR (inc/fields.hpp:142).  A non-positive pivot gives NaN, as in Eigen.
+template <int N>
+class llt_of {
+ public:
+  explicit llt_of(const cmatrix<N, N>& A);
+  cmatrix<N, N> matrixL() const;
+  cmatrix<N, N> matrixU() const;
+
+ private:
+  cplx l_[N * N];
+};
+
+template <int Rows, int Cols>
 class cmatrix {
  public:
   cplx v[Rows * Cols];
@@ -167,6 +203,21 @@ class cmatrix {
     }
   };
   rowwise_proxy rowwise() const { return rowwise_proxy{*this}; }
+  // Eigen's decompositions as the reference's templates call them (square matrices)
+  full_piv_lu<Rows> fullPivLu() const {
+    static_assert(Rows == Cols, "fullPivLu: square matrices");
+    return full_piv_lu<Rows>(*this);
+  }
+  llt_of<Rows> llt() const {
+    static_assert(Rows == Cols, "llt: square matrices");
+    return llt_of<Rows>(*this);
+  }
+  cmatrix inverse() const { return fullPivLu().inverse(); }
+  double norm() const {  // Frobenius norm (a column's 2-norm)
+    double s2 = 0.0;
+    for (int k = 0; k < Rows * Cols; ++k) s2 += std::norm(v[k]);
+    return std::sqrt(s2);
+  }
   // sqrt(sum_j |a_ij|^2) for every row i (Eigen: rowwise().norm())
   void rowwise_norm(double* out) const {
     for (int i = 0; i < Rows; ++i) {
@@ -193,6 +244,106 @@ inline cmatrix<R, C> operator*(const cmatrix<R, K>& a, const cmatrix<K, C>& b) {
     for (int k = 0; k < K; ++k)
       for (int i = 0; i < R; ++i) r(i, j) += a(i, k) * b(k, j);
   return r;
+}
+
+template <int R, int C>
+inline cmatrix<R, C> operator*(cmatrix<R, C> a, double s) { return s * a; }
+template <int R, int C>
+inline cmatrix<R, C> operator*(cplx s, cmatrix<R, C> a) {
+  for (int k = 0; k < R * C; ++k) a.v[k] *= s;
+  return a;
+}
+
+template <int N>
+full_piv_lu<N>::full_piv_lu(const cmatrix<N, N>& A) {
+  for (int k = 0; k < N * N; ++k) w_[k] = A.v[k];
+  for (int i = 0; i < N; ++i) rp_[i] = cp_[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int bi = k, bj = k;
+    double best = -1.0;
+    for (int j = k; j < N; ++j)
+      for (int i = k; i < N; ++i) {
+        const double a = std::norm(w(i, j));
+        if (a > best) {
+          best = a;
+          bi = i;
+          bj = j;
+        }
+      }
+    if (bi != k) {
+      for (int j = 0; j < N; ++j) {
+        const cplx t = w(k, j);
+        w(k, j) = w(bi, j);
+        w(bi, j) = t;
+      }
+      const int t = rp_[k];
+      rp_[k] = rp_[bi];
+      rp_[bi] = t;
+    }
+    if (bj != k) {
+      for (int i = 0; i < N; ++i) {
+        const cplx t = w(i, k);
+        w(i, k) = w(i, bj);
+        w(i, bj) = t;
+      }
+      const int t = cp_[k];
+      cp_[k] = cp_[bj];
+      cp_[bj] = t;
+    }
+    const cplx inv_p = cplx(1.0) / w(k, k);
+    for (int i = k + 1; i < N; ++i) w(i, k) *= inv_p;
+    for (int j = k + 1; j < N; ++j) {
+      const cplx u = w(k, j);
+      for (int i = k + 1; i < N; ++i) w(i, j) -= w(i, k) * u;
+    }
+  }
+}
+template <int N>
+template <int C>
+cmatrix<N, C> full_piv_lu<N>::solve(const cmatrix<N, C>& B) const {
+  cmatrix<N, C> X;
+  cplx y[N];
+  for (int c = 0; c < C; ++c) {
+    for (int i = 0; i < N; ++i) y[i] = B(rp_[i], c);
+    for (int i = 1; i < N; ++i)
+      for (int p = 0; p < i; ++p) y[i] -= w(i, p) * y[p];
+    for (int i = N - 1; i >= 0; --i) {
+      for (int p = i + 1; p < N; ++p) y[i] -= w(i, p) * y[p];
+      y[i] /= w(i, i);
+    }
+    for (int i = 0; i < N; ++i) X(cp_[i], c) = y[i];
+  }
+  return X;
+}
+template <int N>
+cmatrix<N, N> full_piv_lu<N>::inverse() const {
+  return solve(cmatrix<N, N>::Identity());
+}
+
+template <int N>
+llt_of<N>::llt_of(const cmatrix<N, N>& A) {
+  for (int k = 0; k < N * N; ++k) l_[k] = cplx(0.0, 0.0);
+  for (int j = 0; j < N; ++j) {  // column j of L: L(j,j), then L(i > j, j)
+    double d = A(j, j).real();
+    for (int p = 0; p < j; ++p) d -= std::norm(l_[p * N + j]);
+    const double ljj = std::sqrt(d);
+    l_[j * N + j] = ljj;
+    for (int i = j + 1; i < N; ++i) {
+      cplx sacc = A(i, j);
+      for (int p = 0; p < j; ++p) sacc -= l_[p * N + i] * std::conj(l_[p * N + j]);
+      l_[j * N + i] = sacc / ljj;
+    }
+  }
+}
+template <int N>
+cmatrix<N, N> llt_of<N>::matrixL() const {
+  cmatrix<N, N> L;
+  for (int k = 0; k < N * N; ++k) L.v[k] = l_[k];
+  return L;
+}
+template <int N>
+cmatrix<N, N> llt_of<N>::matrixU() const {
+  return matrixL().adjoint();
 }
 
 }  // namespace blockcg

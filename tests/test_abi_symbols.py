@@ -43,7 +43,7 @@ def test_rccl_library_exports_its_header(lib):
     from blockcg_amd import rccl
     rl = rccl.load()
     names = [n for n in _declared("blockcg_rccl.h") if n != "bcg_comm"]
-    assert len(names) == 10 and sorted(rccl.SIGNATURES) == sorted(names)
+    assert len(names) == 12 and sorted(rccl.SIGNATURES) == sorted(names)
     for n in names:
         assert hasattr(rl, n), n
     hdr = open(os.path.join(ROOT, "include", "blockcg_rccl.h")).read()

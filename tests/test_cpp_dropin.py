@@ -93,7 +93,7 @@ def test_benchmark_driver_matches_reference_run(built):
 
 # ---- the reference's UNMODIFIED drivers (north_star: "drops in for benchmark.cpp") ---------------------------------
 REF = "/root/reference"
-DROPIN = {k: os.path.join(ROOT, "oracle", "_ref", k) for k in ("dropin_benchmark", "dropin_tests")}
+DROPIN = {k: os.path.join(ROOT, "oracle", "_ref", k) for k in ("dropin_benchmark", "dropin_tests", "dropin_solver_templates")}
 
 
 def test_unmodified_reference_drivers_compile_against_dropin_headers():
@@ -111,7 +111,9 @@ def test_unmodified_reference_drivers_compile_against_dropin_headers():
     # the include path really has no reference header on it
     mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
     rule = mk[mk.index("_ref/dropin_benchmark:"):mk.index("clean:")]
-    assert "$(REFERENCE)/inc" not in rule
+    # (the one reference header that IS read is the solver templates' own file, named explicitly: the probe pre-defines the
+    #  guards of the reference's fields.hpp / dirac_op.hpp, so those two resolve to the drop-in types)
+    assert "-I$(REFERENCE)/inc" not in rule and rule.count("$(REFERENCE)/inc/") == 2 and "$(REFERENCE)/inc/block_solvers.hpp" in rule
 
 
 def test_eigen_style_residual_expressions():
@@ -147,6 +149,20 @@ def test_unmodified_reference_unit_tests_pass_on_the_gpu():
     r = subprocess.run([DROPIN["dropin_tests"]], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert re.search(r"All tests passed \(\d+ assertions? in \d+ test cases?\)", r.stdout), r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_solver_templates_run_over_the_dropin_types():
+    """The reference's OWN solver templates (inc/block_solvers.hpp: SBCGrQ, BCGrQ, BCG -- unmodified, compiled where they lie)
+    instantiated over the drop-in block_fermion_field / block_matrix / dirac_op: every field primitive they call is a C-ABI
+    call, every m x m expression (fullPivLu().solve, rowwise().norm().array(), Eigen::Array, llt) the drop-in matrix type.
+    What a user solver written in the reference's style gets: the reference's test configuration converges in its 41-44
+    iterations to the reference's acceptance criterion and agrees with the library's own solver."""
+    if not os.path.exists(DROPIN["dropin_solver_templates"]):
+        pytest.skip("oracle/_ref/dropin_solver_templates was not built (needs /root/reference at build time)")
+    r = subprocess.run([DROPIN["dropin_solver_templates"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok") == 3 and "FAILED" not in r.stdout, r.stdout
 
 
 # ---- native multi-GPU driver (examples/multi_gpu_solver.cpp: drop-in headers + libblockcg_rccl.so, no Python) --------

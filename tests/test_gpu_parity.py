@@ -615,10 +615,11 @@ def test_capacity_mode_matches_default_and_oracle(bc, orc, m, dims, ring, walk, 
     field = V * 3 * m * 16
     # what the mode is for: the ring instead of the intermediate field, and none of the two further residual buffers of
     # the shift updates grouped over four iterations (pair_shifts_depth: m = 8, 16; capacity mode groups two, for free)
+    # nor the spare P_0 of the deferred X_0 update (DeferredX0: one more field outside capacity mode)
     # (at m = 16 the ring sweep keeps the fused product's block partials of all its chunks side by side: 1024 blocks x chunks)
     chunks = -(-dims[3] // (ring - 2))
     more_partials = max(0, 1024 * chunks * m * m * 16 - 2048 * 32 * 32 * 16) if m == 16 else 0
-    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (2 * field if m in (8, 16) else 0) - more_partials
+    assert res[0][3] - res[ring][3] == field - field // dims[3] * ring + (3 * field if m in (8, 16) else 0) - more_partials
 
 
 def test_capacity_mode_arguments(bc):
@@ -691,6 +692,33 @@ def test_column_sweep_stencil(bc, orc, m, dims, patch, blocks, sync, bundle, mon
         assert "stencil_form_k_hop4" not in prof and "stencil_form_general" not in prof
 
 
+@pytest.mark.parametrize("m,dims,patch,blocks", [(16, [32, 8, 8, 6], "16,2,2", "32"), (32, [16, 8, 8, 4], "8,2,2", "32")])
+def test_super_patch_tile_order(bc, orc, m, dims, patch, blocks, monkeypatch):
+    """BCG_HOP_SUPER=1 (HopWalk::super; the round-5 traffic experiment, profiles/r05_stencil_super_patch.txt): the patches the
+    eight XCD classes sweep at the same time form a 2 x 2 x 2 super-patch.  Tile order only: the operator is bit-identical
+    to the default order and matches the oracle; the fused Gram product sums the same terms in another block order."""
+    monkeypatch.setenv("BCG_HOP_PATCH", patch)
+    monkeypatch.setenv("BCG_HOP_BLOCKS", blocks)
+    U = orc.fill_gauge(dims, 71)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 72)
+    outs = {}
+    for sup in ("0", "1"):
+        monkeypatch.setenv("BCG_HOP_SUPER", sup)
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, 0.3, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        out = bc.block_fermion_field(ctx, m)
+        D.op(out, B)
+        X = [bc.block_fermion_field(ctx, m)]
+        info = bc.SBCGrQ(X, B, D, [0.0], 0.0, 0.0, max_iterations=3, trace_limit=3, return_info=True)
+        assert ctx.profile().get("stencil_form_k_hop4b", {}).get("count", 0) > 0
+        outs[sup] = (out.download(), info["trace"]["alpha"], X[0].download())
+    assert np.array_equal(outs["0"][0], outs["1"][0])
+    assert rel_err(outs["1"][0], orc.dirac_apply(U, dims, 0.3, Bh)) < TOL_KERNEL
+    assert rel_err(outs["1"][1], outs["0"][1]) < 1e-12 and rel_err(outs["1"][2], outs["0"][2]) < 1e-11
+
+
 def test_fused_true_residual_check(bc, orc, monkeypatch):
     """bcg_true_residuals (test/solvers.cpp:104-116, benchmark.cpp:93-103) in its one-pass form -- second stencil, `-= B`
     and the Gram product fused in the bundle kernel, AX never written (m = 16) -- against the oracle and against the unfused
@@ -754,12 +782,18 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
 @pytest.mark.parametrize("m,dims,depth", [(16, [16, 8, 8, 8], 2), (16, [16, 8, 8, 8], 3), (16, [16, 8, 8, 8], 4), (8, [16, 8, 4, 8], 2),
                                           (8, [16, 8, 4, 8], 3), (8, [16, 8, 4, 8], 4), (32, [16, 4, 4, 6], 2)],
                          ids=["m16-2", "m16-3", "m16-4", "m8-2", "m8-3", "m8-4", "m32-2"])
-def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkeypatch):
+@pytest.mark.parametrize("defer_x0", [0, 1], ids=["x0-every-iteration", "x0-deferred"])
+def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, defer_x0, monkeypatch):
     """The shifts >= 1 are updated `depth` iterations at a time (blockcg_capi.hip: pair_shifts_depth, k_phaseC_multi).
     After any number of iterations -- a multiple of the depth or not, run in one call or in pieces, with shifts leaving the
     active set on the way -- X and the residual must equal, bit for bit, those of the solver that updates every shift in
-    every iteration (BCG_PAIR_SHIFTS=0), and match the oracle."""
+    every iteration (BCG_PAIR_SHIFTS=0), and match the oracle.
+    x0-deferred (the default at m = 8, 16: DeferredX0 in blockcg_capi.hip): X_0's updates wait for the closing pass as
+    well, composed onto the group's first P_0 -- the P_0 sequence, the residual, every X_s with s >= 1 stay bit-identical,
+    X_0 agrees to rounding (1e-13), and a group moves 3 (g - 1) + g + 4 S + 1 field passes."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    monkeypatch.setenv("BCG_DEFER_X0", str(defer_x0))
+    deferred = bool(defer_x0) and m != 32
     shifts, mass = [0.0, 1e-3, 0.1, 2.0], 0.2
     S = len(shifts)
     U = orc.fill_gauge(dims, 61)
@@ -784,8 +818,12 @@ def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkey
         b, rb, pb = run(0, pieces, eps_shifts)
         assert ra == rb
         for s in range(S):
-            assert np.array_equal(a[s], b[s]), (pieces, eps_shifts, s)
-        assert not any(k.startswith("phaseC_multi") for k in pb)
+            if s == 0 and deferred:
+                assert rel_err(a[0], b[0]) < 1e-13, (pieces, eps_shifts)
+            else:
+                assert np.array_equal(a[s], b[s]), (pieces, eps_shifts, s)
+        assert not any(k.startswith("phaseC_multi") for k in pb) and "phaseC_p0" not in pb
+        assert ("phaseC_p0" in pa) == (deferred and max(pieces) >= 2)
         if eps_shifts == 0.0:
             # every call runs its iterations in groups of `depth`, the rest as one smaller group (or a plain iteration)
             groups = [g for n in pieces for g in [depth] * (n // depth) + [n % depth] if g > 0]
@@ -798,7 +836,8 @@ def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, monkey
                 # a group of g iterations moves 5 (g - 1) + g + 4 S field passes where g plain ones move g (1 + 4 S)
                 per_pass = pb["phaseC"]["bytes"] / (sum(pieces) * (1 + 4 * S))
                 moved = sum(v["bytes"] for k, v in pa.items() if k.startswith("phaseC"))
-                want = sum(5 * (g - 1) + g + 4 * S if g >= 2 else 1 + 4 * S for g in groups)
+                inner = 3 if deferred else 5  # shift 0 inside a group: Q, P_0 read, P_0 written [+ X_0 read and written]
+                want = sum(inner * (g - 1) + g + 4 * S + (1 if deferred else 0) if g >= 2 else 1 + 4 * S for g in groups)
                 assert moved == pytest.approx(per_pass * want, rel=1e-9)
     # shifts did leave the active set in the runs with eps_shifts > 0 (otherwise those runs test nothing new)
     o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 3e-2, max_iterations=9, trace_limit=9)
@@ -869,9 +908,11 @@ def test_grouped_shift_updates_with_more_shifts_than_one_launch_holds(bc, orc, m
         st.iterate(9)
         st.end()
         outs[pair] = ([x.download() for x in X], ctx.profile())
-    for s in range(len(shifts)):
+    assert rel_err(outs[4][0][0], outs[0][0][0]) < 1e-13  # X_0: deferred, composed products (DeferredX0)
+    for s in range(1, len(shifts)):
         assert np.array_equal(outs[4][0][s], outs[0][0][s]), s
-    assert outs[4][1]["phaseC_multi4"]["count"] == 4 and "phaseC_multi4" not in outs[0][1]  # two groups of four, two launches each
+    # two groups of four, two launches each (the first takes three shifts besides shift 0: its four composed matrices need room)
+    assert outs[4][1]["phaseC_multi4"]["count"] == 4 and "phaseC_multi4" not in outs[0][1]
     o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=9)
     for s in range(len(shifts)):
         assert rel_err(outs[4][0][s], o["X"][s]) < 1e-10

@@ -105,11 +105,12 @@ def test_half_volume_memory_and_rejections():
         bc.block_fermion_field(bc.Context([6, 3, 4, 4]), 4, parity=0)
     full = bc.block_fermion_field(ctx, 16)
     assert ctx.lib.bcg_field_parity(full.h) == -1
-    # the memory plan of one half-volume solve at 64^4, m = 16, 4 shifts (source consumed): 13 half fields (X_s, P_s, Q, T,
-    # tmp and the two further residual buffers of the grouped shift updates) + full links, against 13 full fields
+    # the memory plan of one half-volume solve at 64^4, m = 16, 4 shifts (source consumed): 14 half fields (X_s, P_s, Q, T,
+    # tmp, the two further residual buffers of the grouped shift updates and the spare P_0 of the deferred X_0 update) + full
+    # links, against 14 full fields
     big = bc.Context([64, 64, 64, 64])
     half, whole = big.sbcgrq_device_bytes_half(16, 4, consume_B=True), big.sbcgrq_device_bytes(16, 4, consume_B=True)
-    assert 92e9 < half < 95e9 and 176e9 < whole < 179e9 and half < 0.54 * whole
+    assert 99e9 < half < 101e9 and 189e9 < whole < 192e9 and half < 0.54 * whole
 
 
 @pytest.mark.parametrize("m,dims,patch", [(16, [64, 8, 8, 6], "16,2,2"), (32, [32, 8, 8, 4], "8,2,2")], ids=["m16", "m32"])

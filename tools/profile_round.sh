@@ -26,6 +26,6 @@ python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/prof/bench_final.json").read().strip().splitlines()[-1])
 n=d["steps"]
-print(json.dumps({k:d[k] for k in ("value","ms_per_step","iterations_per_sec","hbm_roofline_frac_whole_iteration","roofline","cpu_baseline")}, indent=1))
+print(json.dumps({k:d[k] for k in ("value","ms_per_step","iterations_per_sec","hbm_GBps_algorithmic","hbm_GBps_moved_per_gpu","hbm_GBps_pmc_per_gpu","roofline","cpu_baseline")}, indent=1))
 print({k: round(v/n,2) for k,v in d["kernel_ms"].items()})
 PY
