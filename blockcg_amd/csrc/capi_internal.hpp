@@ -137,7 +137,8 @@ int upload_mat(bcg_context* c, const CMat& M, const double2** dev_out);
 bool same_shape(const bcg_field* a, const bcg_field* b);
 inline bool fast_rows(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_width(m); }       // + Gram, phase B
 inline bool fast_rmul(const bcg_context* c, int m) { return !c->force_generic && bcg::mfma_rows_width(m); }  // products, phase C
-inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m); }
+// (the specialised stencil kernels: 4-D lattices whose L0 is a multiple of the tile; everything else is k_hop_generic)
+inline bool fast_hop(const bcg_context* c, int m) { return !c->force_generic && bcg::hop_fast_width(m) && bcg::hop_can_split_tiles(m, c->lat); }
 // Block partials in c->partials -> G (m x m), summed over blocks in a fixed order and over ranks, Hermitian-mirrored
 int finish_gram(bcg_context* c, int m, int nblocks, CMat& G, bool mirror, bool folded = false);
 int gram(bcg_context* c, const bcg_field* a, const bcg_field* b, CMat& G, bool mirror = true);  // G = a^dagger b

@@ -57,49 +57,16 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, 
   const int64_t ntiles = (rows + 15) / 16;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
   int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
-  // AHEAD: the next tile's loads in flight while this one is multiplied (m <= 16; BCG_PHASEB_AHEAD tuning build).  Off:
-  // measured over repeated bench runs on one device (tools/ab_bench.sh, profiles/r03_phaseB_ab.txt) the kernel with it
-  // took 7.3 ms in some processes and 8.1 ms in others, without it 7.16-7.25 ms in all of them.
-#ifdef BCG_PHASEB_AHEAD
-  constexpr bool AHEAD = M <= 16;
-#else
-  constexpr bool AHEAD = false;
-#endif
-  // LINB (m = 16): T and Q are loaded as contiguous memory and change ownership through the wave's buffer; the new Q is
-  // stored from the values the Gram product reads back from that buffer, which ARE the contiguous order (element
-  // lane + 64 g is row 4 g + (lane >> 4), column lane & 15): no extra LDS traffic for the store.
-  // Measured (profiles/r03_contiguous_tile_moves.txt): no gain -- 7.47-7.88 ms against 7.1-7.5 -- so off (BCG_PHASEB_LIN build).
-#ifdef BCG_PHASEB_LIN
-  constexpr bool LINB = M == 16 && !AHEAD;
-#else
-  constexpr bool LINB = false;
-#endif
+  // Two tuning builds of rounds 2-3 are gone with their switches (measured, profiles/r03_phaseB_ab.txt and
+  // r03_contiguous_tile_moves.txt): the next tile's loads in flight during the products (7.3 ms in some processes, 8.1 ms
+  // in others, against 7.16-7.25 ms in all of them without), and T / Q moved as contiguous memory through the wave's
+  // ownership buffer (7.47-7.88 ms against 7.1-7.5).
   Tile<M> t, q;
-  if (AHEAD && tile < ntiles) {
-    tile_load<M>(t, T, tile * 16 + r, kq, tile * 16 + r < rows);
-    tile_load<M>(q, Q, tile * 16 + r, kq, tile * 16 + r < rows);
-  }
   for (; tile < ntiles; tile += stride) {
     const int64_t row = tile * 16 + r;
     const bool ok = BCG_ROW_OK(row, rows);
-    if (LINB) {
-      tile_load_lin<M>(t, T, tile, rows, lane);
-      tile_load_lin<M>(q, Q, tile, rows, lane);
-      lin_to_mfma<M>(t, tw, lane);
-      lin_to_mfma<M>(q, tw, lane);
-    } else if (!AHEAD) {
-      tile_load<M>(t, T, row, kq, ok);
-      tile_load<M>(q, Q, row, kq, ok);
-    }
-    // the next tile's loads are in flight while this one is multiplied, transposed and accumulated (m <= 16: the
-    // registers allow it; at m = 32 the two extra tiles would cost the third block per CU)
-    Tile<M> tn, qn;
-    const int64_t nrow = (tile + stride) * 16 + r;
-    const bool nok = tile + stride < ntiles && nrow < rows;
-    if (AHEAD && tile + stride < ntiles) {
-      tile_load<M>(tn, T, nrow, kq, nok);
-      tile_load<M>(qn, Q, nrow, kq, nok);
-    }
+    tile_load<M>(t, T, row, kq, ok);
+    tile_load<M>(q, Q, row, kq, ok);
     if (rinv) {  // q <- q rho_prev^-1: exactly what phase C computes for its own use
       Acc<M> A0;
       acc_zero<M>(A0);
@@ -110,24 +77,18 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, 
     acc_from_tile<M>(A, q);
     rmul_acc<M>(A, t, Ml, lane);
     tile_from_acc<M>(q, A);
-    if (!LINB) tile_store<M>(q, Qout, row, kq, ok);
+    tile_store<M>(q, Qout, row, kq, ok);
     // transpose the new tile through LDS: write (r, j = 4s+kq), read (row = 4g + (l>>4), j = l&15 + 16 jb)
 #pragma unroll
     for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = q.v[s];
     // same wave wrote and reads: no barrier needed, only LDS ordering (ds ops of one wave are in order)
-    double2* const qtile = Qout + tile * (16 * M);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       double2 a[JB];
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb)
         a[jb] = *reinterpret_cast<const double2*>(tw + (4 * g + (lane >> 4)) * TLD + 2 * (16 * jb + (lane & 15)));
-      if (LINB && tile * 16 + 4 * g + (lane >> 4) < rows) qtile[lane + 64 * g] = a[0];
       gram_step<M>(G, a, a);
-    }
-    if (AHEAD && tile + stride < ntiles) {
-      t = tn;
-      q = qn;
     }
   }
   gram_block_store<M, NW>(G, scratch, partials, tid, gf.out != nullptr);

@@ -98,7 +98,7 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
                     const HopWindow& win = HopWindow());
 // true when launch_hop_fast can process interior (tile_class 1) and boundary (2) tiles in separate launches
 bool hop_can_split_tiles(int m, const LatticeDev& lat);
-// Which kernel launch_hop_fast will use: 0 general (k_hop_fast), 1 k_hop4 (tile counter), 2 k_hop4c (column sweep), -1 rejected
+// Which kernel launch_hop_fast will use: 0 none (the caller runs k_hop_generic), 1 k_hop4 (tile counter), 2 k_hop4c (column sweep), -1 rejected
 int hop_kernel_form(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, int tile_class, const HopWindow& win);
 // true when a whole launch (tile class 0) with the fused Gram product folds its partials itself (HopTuning::fold honoured)
 bool hop_folds_gram(int m, const LatticeDev& lat, int max_blocks, const HopTuning& tune, const HopWindow& win);

@@ -1,5 +1,5 @@
 // The stencil of the MFMA fast path for gfx950 (MI355X): dirac_op::D (inc/dirac_op.hpp:14-21) and its fused forms, block
-// widths m = 8, 16, 32 -- k_hop_fast (any lattice), k_hop4 / k_hop4c (4-D tile and column forms, tile classes of the split
+// widths m = 8, 16, 32 -- k_hop4 / k_hop4c (4-D tile and column forms, tile classes of the split
 // halo exchange) and k_hop4b (2 x 2 column bundles: the software-pipelined, broadcast-link step; ring windows; the
 // checkerboard form for half-volume fields) -- with their launchers.  Shared helpers: mfma_common.hpp.
 #include "mfma_common.hpp"
@@ -17,14 +17,10 @@ typedef __attribute__((address_space(3))) char lds_char_t;
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_char_t*)p));
 }
-#ifndef BCG_HOP4B_INCR
-#define BCG_HOP4B_INCR 1  // carry the step's addresses along a column instead of recomputing them (0: tuning / A-B build)
-#endif
-#ifndef BCG_HOP4B_INCR_WRAP
-#define BCG_HOP4B_INCR_WRAP 1  // ... the wrap row of a column's last slice too: 0 never (closed form inside the sweep), 2 always,
-                               // 1 where measured faster -- plain hop 10.05-10.23 vs 10.31-10.49 ms, with the fused Gram
-                               // product 12.05-12.37 vs 11.90-12.16 (profiles/r03_stencil_incremental_addresses.txt)
-#endif
+// Settled in earlier rounds and no longer switches (profiles/r03_stencil_incremental_addresses.txt, r04_stencil_spread.txt):
+// the step's addresses are carried along a column instead of recomputed (INCR), the wrap row of a column's last slice too
+// in the forms without the fused Gram product (plain hop 10.05-10.23 vs 10.31-10.49 ms; with the product 12.05-12.37 vs
+// 11.90-12.16), and the plain form issues its vector-memory instructions grouped (SPREAD 0; the shifted forms: SPREAD below).
 // PIPE: the software-pipelined schedule of the bundle sweep (m = 16, 32; full-lattice form): every global access of a step is
 // an operation hipcc does not see, issued where it pays and retired by hand-counted s_waitcnt -- see "PIPE" in hop4b_body.
 // -DBCG_HOP4B_PIPE=0 is the A/B build: the step of rounds 1-3 (still what m = 8 and the residual form run).
@@ -50,9 +46,6 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 // along every accumulation chain: bit-identical.  -DBCG_HOP4B_BCAST=0: the per-lane reads (A/B build).
 #ifndef BCG_HOP4B_BCAST
 #define BCG_HOP4B_BCAST 1
-#endif
-#ifndef BCG_HOP4B_SPREAD_PLAIN
-#define BCG_HOP4B_SPREAD_PLAIN 0
 #endif
 __device__ __forceinline__ void glds16_link(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -130,142 +123,10 @@ __device__ __forceinline__ void st_nt(double2* p, double2 v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stencil (K1), general form: any number of dimensions and any extents (the specialised 4-D kernel below
-// takes over when L0 is a multiple of the tile).  Block = 256 threads = 4 waves; wave = 64/M sites x M
-// right-hand sides, lane = (site, j).  The 2*ndim links of the block's sites are staged once per tile in
-// LDS by one thread per link (144 contiguous bytes) and read as LDS broadcasts, instead of every lane
-// fetching every link from global memory.  Blocks walk the lattice in lexicographic tiles of SPB sites.
-// MODE HOP_SHIFTED: out = c0*p - D in; with GRAM (m = 16) also accumulates p^dagger out.
+// (The general form of the stencil for m = 8, 16, 32 -- k_hop_fast: any number of dimensions and extents, links staged per
+// tile in LDS -- was retired in round 5: lattices the specialised 4-D kernels below do not take (fewer than four dimensions,
+// L0 not a multiple of the tile) run k_hop_generic like every other width; measured in profiles/r05_retired_general_stencil.txt.)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void coords_of(const LatticeDev& lat, int64_t site, int x[4]) {
-  x[0] = static_cast<int>(site % lat.L[0]); site /= lat.L[0];
-  x[1] = static_cast<int>(site % lat.L[1]); site /= lat.L[1];
-  x[2] = static_cast<int>(site % lat.L[2]); site /= lat.L[2];
-  x[3] = static_cast<int>(site);
-}
-__device__ __forceinline__ int64_t face_idx(const LatticeDev& lat, const int x[4], int mu) {
-  int64_t f = 0, st = 1;
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu) {
-    if (nu == mu) continue;
-    f += x[nu] * st;
-    st *= lat.L[nu];
-  }
-  return f;
-}
-
-template <int M, int MODE, bool GRAM>
-__global__ void __launch_bounds__(256) k_hop_fast(LatticeDev lat, const double2* __restrict__ U,
-                                                  const double2* __restrict__ Ughost, const double2* __restrict__ in,
-                                                  const double2* __restrict__ ghost, double2* __restrict__ out,
-                                                  const double2* __restrict__ p, double c0,
-                                                  double2* __restrict__ partials, int64_t ntiles) {
-  static_assert(!GRAM || M == 16, "fused Gram accumulation needs lane&15 == rhs index");
-  constexpr int SPW = 64 / M;
-  constexpr int SPB = 4 * SPW;
-  constexpr int NW = 4;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double2* Us = reinterpret_cast<double2*>(smem);  // [SPB][4 mu][2 dir][9]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sl = wave * SPW + lane / M;
-  const int j = lane % M;
-  GramAcc<16> G;
-  if (GRAM) gram_zero(G);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t site0 = tile * SPB;
-    __syncthreads();
-    // ---- stage links: thread e = (site s, mu, dir) copies one 3x3 link
-    if (tid < SPB * lat.ndim * 2) {
-      const int dir = tid & 1;
-      const int mu = (tid >> 1) % lat.ndim;
-      const int s = (tid >> 1) / lat.ndim;
-      const int64_t site = site0 + s;
-      if (site < lat.V) {
-        const double2* src;
-        if (dir == 0) {
-          src = U + (site * lat.ndim + mu) * 9;
-        } else {
-          int x[4];
-          coords_of(lat, site, x);
-          if (x[mu] > 0) src = U + ((site - lat.stride[mu]) * lat.ndim + mu) * 9;
-          else if (!lat.split[mu]) src = U + ((site + (lat.L[mu] - 1) * lat.stride[mu]) * lat.ndim + mu) * 9;
-          else src = Ughost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 9;
-        }
-        double2* dst = Us + ((s * 4 + mu) * 2 + dir) * 9;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dst[k] = src[k];
-      }
-    }
-    __syncthreads();
-    // ---- compute
-    const int64_t site = site0 + sl;
-    const bool ok = site < lat.V;
-    double2 acc[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-    if (ok) {
-      int x[4];
-      coords_of(lat, site, x);
-      int parity = 0;
-      for (int mu = 0; mu < lat.ndim; ++mu) {
-        const double eta = (parity & 1) ? -1.0 : 1.0;
-        const double2* pf;
-        if (x[mu] + 1 < lat.L[mu]) pf = in + (site + lat.stride[mu]) * 3 * M;
-        else if (!lat.split[mu]) pf = in + (site - (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
-        else pf = ghost + (lat.ghost_off[mu][1] + face_idx(lat, x, mu)) * 3 * M;
-        const double2* pb;
-        if (x[mu] > 0) pb = in + (site - lat.stride[mu]) * 3 * M;
-        else if (!lat.split[mu]) pb = in + (site + (lat.L[mu] - 1) * lat.stride[mu]) * 3 * M;
-        else pb = ghost + (lat.ghost_off[mu][0] + face_idx(lat, x, mu)) * 3 * M;
-        double2 f[3], bk[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          f[k] = pf[k * M + j];
-          bk[k] = pb[k * M + j];
-        }
-        const double2* uf = Us + ((sl * 4 + mu) * 2 + 0) * 9;
-        const double2* ub = Us + ((sl * 4 + mu) * 2 + 1) * 9;
-        double2 t[3] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const double2 u = uf[k * 3 + r];   // U(r,k)
-            t[r].x = fma(u.x, f[k].x, t[r].x); t[r].x = fma(-u.y, f[k].y, t[r].x);
-            t[r].y = fma(u.x, f[k].y, t[r].y); t[r].y = fma(u.y, f[k].x, t[r].y);
-            const double2 v = ub[r * 3 + k];   // U_b(k,r); subtract conj(v) * psi_b(k)
-            t[r].x = fma(-v.x, bk[k].x, t[r].x); t[r].x = fma(-v.y, bk[k].y, t[r].x);
-            t[r].y = fma(-v.x, bk[k].y, t[r].y); t[r].y = fma(v.y, bk[k].x, t[r].y);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          acc[r].x = fma(eta, t[r].x, acc[r].x);
-          acc[r].y = fma(eta, t[r].y, acc[r].y);
-        }
-        parity += x[mu] + lat.origin[mu];
-      }
-    }
-    double2 pv[3], tv[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int64_t o = (site * 3 + r) * M + j;
-      if (MODE == HOP_PLAIN) {
-        tv[r] = make_double2(0.5 * acc[r].x, 0.5 * acc[r].y);
-        if (ok) out[o] = tv[r];
-      } else {
-        pv[r] = ok ? p[o] : make_double2(0.0, 0.0);
-        tv[r] = make_double2(fma(c0, pv[r].x, -0.5 * acc[r].x), fma(c0, pv[r].y, -0.5 * acc[r].y));
-        if (ok) out[o] = tv[r];
-        else tv[r] = make_double2(0.0, 0.0);
-      }
-    }
-    if (GRAM) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) gram_step<16>(G, &pv[r], &tv[r]);
-    }
-  }
-  if (GRAM) gram_block_store<16, NW>(G, smem, partials, tid);
-}
-
 // ---------------------------------------------------------------------------------------------------
 struct TileGeom {
   int x0b, x1, x2, x3;   // coordinates of the tile's first site
@@ -402,18 +263,9 @@ __global__ void __launch_bounds__(256) k_hop4(LatticeDev lat, const double2* __r
   // capacity mode (HopWindow::ring): the intermediate field is a ring of x3 slices, written by HOP_PLAIN, read by HOP_SHIFTED
   constexpr bool RING_OUT = RING && MODE == HOP_PLAIN;
   constexpr bool RING_IN = RING && MODE == HOP_SHIFTED;
-#ifndef BCG_HOP4_CARRY_PLAIN
-#define BCG_HOP4_CARRY_PLAIN 0
-#endif
-#ifndef BCG_HOP4_CARRY_B3
-#define BCG_HOP4_CARRY_B3 1
-#endif
-#ifndef BCG_HOP4_CARRY_U3
-#define BCG_HOP4_CARRY_U3 1
-#endif
-  constexpr bool CARRY = GRAM || BCG_HOP4_CARRY_PLAIN;
-  constexpr bool CARRY_B3 = CARRY && BCG_HOP4_CARRY_B3;   // -x3 neighbours from the register history
-  constexpr bool CARRY_U3 = CARRY && BCG_HOP4_CARRY_U3;   // U_3(x-3) from the previous link image
+  constexpr bool CARRY = GRAM;
+  constexpr bool CARRY_B3 = CARRY;   // -x3 neighbours from the register history
+  constexpr bool CARRY_U3 = CARRY;   // U_3(x-3) from the previous link image
   constexpr int STAGES = CARRY_U3 ? 3 : 2;
   // run-time variants in this kernel cost registers (256 VGPRs with one extra branch): none kept
   constexpr int SPW = 64 / M;
@@ -1519,7 +1371,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
     // step, as many as the step has FMAs.
     // In capacity mode the ring-addressed side (the output of the plain hop, the input rows of the shifted one) keeps the
     // closed form; links, p and the other side are carried.
-    constexpr bool INCR = BCG_HOP4B_INCR != 0 && SHARE && !CB;  // (PIPE below builds on it)
+    constexpr bool INCR = SHARE && !CB;  // (PIPE below builds on it)
     constexpr bool INCR_IN = INCR && !RING_IN, INCR_OUT = INCR && !RING_OUT;
     const int64_t id_f = static_cast<int64_t>(S3) * (36 * 16), id_row = static_cast<int64_t>(S3) * RB;
     const char* ik_f = nullptr; const char* ik_l = nullptr; const char* ik_1 = nullptr; const char* ik_2 = nullptr;
@@ -1607,7 +1459,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
       // link DMAs of this wave (checkerboard form: the forward links and all four directions' backward links, every wave)
       const int nC = CB ? RFW + 4 * RBK : RFW + 1 + (e1 ? 0 : RBK) + (e2 ? 0 : RBK);
       constexpr int nD = 6, nS = 3;
-      constexpr int SPREAD = MODE == HOP_PLAIN ? BCG_HOP4B_SPREAD_PLAIN : BCG_HOP4B_SPREAD;  // 1: rows, 2: links, 4: second next-row group
+      constexpr int SPREAD = MODE == HOP_PLAIN ? 0 : BCG_HOP4B_SPREAD;  // 1: rows, 2: links, 4: second next-row group
       constexpr bool SP_B = (SPREAD & 1) != 0, SP_C = (SPREAD & 2) != 0, SP_D = (SPREAD & 4) != 0;
       (void)nB;
       for (int x3 = win.x3_lo; x3 < x3_end; ++x3) {
@@ -2028,7 +1880,7 @@ __device__ __forceinline__ void hop4b_body(const LatticeDev& lat, const double2*
           own = ir_own;
           hal = (hs ? ir_rgt : ir_lft) + hj * 16;
           ir_own += id_row; ir_lft += id_lft; ir_rgt += id_rgt;
-        } else if (INCR_IN && (BCG_HOP4B_INCR_WRAP == 1 ? !GRAM : BCG_HOP4B_INCR_WRAP != 0)) {
+        } else if (INCR_IN && !GRAM) {
           own = iw_own;
           hal = (hs ? iw_rgt : iw_lft) + hj * 16;
         } else {
@@ -2489,28 +2341,8 @@ int launch_hop_fast(hipStream_t s, int m, const LatticeDev& lat, const double2* 
     if (m == 16) return launch_hop4<16>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
     return launch_hop4<32>(s, lat, U, Ughost, in, ghost, out, mode, p, c0, partials, gram, mb, tune, tile_class, win);
   }
-  if (win.x3_n > 0 || win.ring > 0 || win.cb || mode == HOP_RESID) return -1;  // specialised kernel only
-  if (tile_class != 0) return -1;  // only the specialised kernel can split interior / boundary tiles
-  const int64_t ntiles = (lat.V + spb - 1) / spb;
-  const int grid = grid_tiles(ntiles, 1, max_blocks);
-  const size_t lds_u = sizeof(double2) * spb * 4 * 2 * 9;
-  const size_t lds_g = gram ? sizeof(double) * 4 * 8 * 64 : 0;
-  const size_t lds = lds_u > lds_g ? lds_u : lds_g;
-#define BCG_HOP(MM)                                                                                                         \
-  {                                                                                                                         \
-    if (mode == HOP_PLAIN)                                                                                                  \
-      hipLaunchKernelGGL((k_hop_fast<MM, HOP_PLAIN, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out, \
-                         p, c0, partials, ntiles);                                                                          \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((k_hop_fast<MM, HOP_SHIFTED, false>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost,    \
-                         out, p, c0, partials, ntiles);                                                                     \
-  }
-  if (gram && m == 16 && mode == HOP_SHIFTED) {
-    hipLaunchKernelGGL((k_hop_fast<16, HOP_SHIFTED, true>), dim3(grid), dim3(256), lds, s, lat, U, Ughost, in, ghost, out,
-                       p, c0, partials, ntiles);
-  } else if (m == 8) BCG_HOP(8) else if (m == 16) BCG_HOP(16) else BCG_HOP(32)
-#undef BCG_HOP
-  return grid;
+  (void)spb;
+  return -1;  // no specialised form for this lattice: the caller runs k_hop_generic
 }
 
 }  // namespace bcg
