@@ -411,6 +411,11 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
   }
   const int par_p = half ? P->parity : -1, par_t = half ? half_tmp->parity : -1;
   const int vden = half ? 2 * L3 : L3;  // a window's share of the full local volume
+  // Algorithmic link bytes of a launch on HALF fields: every output site needs its four forward links AND the four backward
+  // links U_mu(x - mu), which live at sites of the other parity and are nobody's forward link in this launch -- a half-volume
+  // stencil reads ALL the lattice's links, 2 x 576 B per output site, where the full-volume one reads each link once for two
+  // uses.  (Rounds 3-4 priced one pass: the checkerboard form's "0.44 / 0.49 of the HBM peak" was 27 % / 20 % under-priced.)
+  const double kLinkPasses = half ? 2.0 : 1.0;
   auto window = [&](int lo, int n, int parity_out) {
     bcg::HopWindow w;
     w.x3_lo = lo;
@@ -468,7 +473,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     } else {
       note_stencil_form(c, m, 0, window(lo, n, 0), /*plain=*/true);
     }
-    ProfScope ps(c, half ? "hop_half" : "hop_ring", alg_bytes(c, m, 2, 1, n, vden), hop_flops(c, m, false, n, vden));
+    ProfScope ps(c, half ? "hop_half" : "hop_ring", alg_bytes(c, m, 2, kLinkPasses, n, vden), hop_flops(c, m, false, n, vden));
     const int nb = bcg::launch_hop_fast(c->stream, m, lat, g->U, g->Ughost, P->d, c->halo_recv, ring, bcg::HOP_PLAIN, nullptr,
                                         0.0, c->partials, false, kFastBlocks, tune, 0, window(lo, n, par_t));
     if (nb < 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "capacity mode: stencil window rejected");
@@ -480,7 +485,7 @@ int apply_shifted_ring(bcg_context* c, const bcg_gauge* g, double mass, double s
     {
       if (half && c->profiling) c->prof["stencil_form_k_hop4b_checkerboard"].count += 1;
       ProfScope ps(c, half ? (gram ? "hop_half_shifted_gram" : "hop_half_shifted") : (gram ? "hop_shifted_gram_ring" : "hop_shifted_ring"),
-                   alg_bytes(c, m, 3, 1, hi - lo, vden), hop_flops(c, m, gram, hi - lo, vden));
+                   alg_bytes(c, m, 3, kLinkPasses, hi - lo, vden), hop_flops(c, m, gram, hi - lo, vden));
       const int nb = bcg::launch_hop_fast(c->stream, m, lat, g->U, g->Ughost, ring, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                           c0, c->partials + static_cast<size_t>(total) * m * m, gram, kFastBlocks, tune, 0,
                                           window(lo, hi - lo, par_p));
@@ -560,6 +565,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
     BCG_TRY(get_tmp_half(c, m, 1 - P->parity, &tmp));
     BCG_TRY(halo_gauge(c, const_cast<bcg_gauge*>(g)));
     // the bundle sweep in its checkerboard form (m = 16, compact row a multiple of the tile, patch walk), else the generic kernel
+    // (algorithmic bytes of these launches: two link passes per half site -- all the lattice's links, see apply_shifted_ring)
     bcg::LatticeDev latc = c->lat;
     latc.L[0] /= 2;
     latc.V /= 2;
@@ -602,7 +608,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
       w.cb = 1;
       w.cb_parity = tmp->parity;
       {
-        ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2), hop_flops(c, m, false, 1, 2));
+        ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 2, 1, 2), hop_flops(c, m, false, 1, 2));
         nb1 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0,
                                    c->partials, false, kFastBlocks, c->hop_tune, 0, w);
       }
@@ -615,7 +621,7 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
         if (fold) tune.fold = bcg::GramFold{c->dev_gram, c->fold_tickets};
         w.cb_parity = T->parity;
         {
-          ProfScope ps(c, gram ? "hop_half_shifted_gram" : "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2), hop_flops(c, m, gram, 1, 2));
+          ProfScope ps(c, gram ? "hop_half_shifted_gram" : "hop_half_shifted", alg_bytes(c, m, 3, 2, 1, 2), hop_flops(c, m, gram, 1, 2));
           nb2 = bcg::launch_hop_fast(c->stream, m, latc, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                                      mass * mass + sigma0, c->partials, gram, kFastBlocks, tune, 0, w);
         }
@@ -630,13 +636,13 @@ int apply_shifted(bcg_context* c, const bcg_gauge* g, double mass, double sigma0
       }
     }
     {
-      ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 1, 1, 2), hop_flops(c, m, false, 1, 2));
+      ProfScope ps(c, "hop_half", alg_bytes(c, m, 2, 2, 1, 2), hop_flops(c, m, false, 1, 2));
       bcg::launch_hop_half(c->stream, m, c->lat, tmp->parity, g->U, g->Ughost, P->d, c->halo_recv, tmp->d, bcg::HOP_PLAIN, nullptr, 0.0);
     }
     BCG_TRY(check_launch(c, "hop_half"));
     BCG_TRY(halo_field(c, tmp));
     {
-      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 1, 1, 2), hop_flops(c, m, false, 1, 2));
+      ProfScope ps(c, "hop_half_shifted", alg_bytes(c, m, 3, 2, 1, 2), hop_flops(c, m, false, 1, 2));
       bcg::launch_hop_half(c->stream, m, c->lat, T->parity, g->U, g->Ughost, tmp->d, c->halo_recv, T->d, bcg::HOP_SHIFTED, P->d,
                            mass * mass + sigma0);
     }
