@@ -515,7 +515,10 @@ def main():
             sys.exit("--ladder strong is the fixed lattice 64^4 over the GPUs: no shape flags")
         from blockcg_amd.comm import grid_for
         sgrid = grid_for(world, 4) if world > 1 else [1, 1, 1, 1]
-        args.local_dims, args.capacity = [64 // g for g in sgrid], 0
+        total = [64, 64, 64, 64]
+        if os.environ.get("BCG_BENCH_STRONG_DIMS"):  # rehearsal aid: a smaller fixed lattice (several ranks on one test GPU)
+            total = [int(x) for x in os.environ["BCG_BENCH_STRONG_DIMS"].split(",")]
+        args.local_dims, args.capacity = [t // g for t, g in zip(total, sgrid)], 0
     default_shape = (args.local_dims is None and args.capacity is None) or strong
     args.local_dims, args.capacity, headline_ladder = resolve_shape(world, args.local_dims, args.capacity, args.half)
     headline_ladder = headline_ladder and not strong

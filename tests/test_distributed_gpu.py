@@ -280,6 +280,28 @@ def test_bare_bench_command_half_volume_option():
     assert "halo_exchange" not in comm  # every exchange of the timed region in the split form
 
 
+def test_bare_bench_command_strong_scaling_ladder():
+    """`python bench.py --gpus 4 --ladder strong`: the lattice stays what it is at N = 1 and is divided over the ranks
+    (process grid (1,1,2,2): x3 divided, so no ring -- the split exchange overlaps the interior tiles instead), `scaling`
+    says strong.  Four ranks on GPU 0 over the native transport's stand-in, on a rehearsal-sized lattice."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BCG_BACKEND="rccl", BCG_RCCL_LIB=_mock_transport(), BCG_DEVICE="0", OMP_NUM_THREADS="1", BCG_HOP_BLOCKS="32",
+               BCG_HOP_PATCH="16,2,2", BCG_BENCH_TIMEOUT="500", BCG_BENCH_STRONG_DIMS="32,8,16,16")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--ladder", "strong", "--steps", "4", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    _sweep_mock_files()
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 4 and d["capacity_ring_slices"] == 0 and d["value"] > 0
+    assert d["config"]["global_dims"] == [32, 8, 16, 16] and d["config"]["process_grid"] == [1, 1, 2, 2]
+    assert "strong-scaling ladder" in d["config"]["workload"] and len(d["config"]["memory_ladder"]) == 1
+    comm = d["comm_ms_per_iteration"]
+    assert comm and comm["allreduce"] > 0 and comm["halo_exchange_begin"] > 0  # the split exchange overlaps the interior tiles
+
+
 @pytest.mark.parametrize("how", ["begin_fails_on_one_rank", "free_memory_too_small"])
 def test_bare_bench_command_steps_down_the_memory_ladder(how):
     """`python bench.py --gpus 4 --step-down` with less memory than the first rungs need (BCG_DEBUG_FIELD_BUDGET, the
