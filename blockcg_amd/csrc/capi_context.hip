@@ -369,7 +369,6 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
   if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)
   if (const char* e = std::getenv("BCG_DEFER_X0")) c->defer_x0 = std::atoi(e) != 0;   // deferred update of X_0 (DeferredX0)
-  if (const char* e = std::getenv("BCG_FIELD_STAGGER")) c->field_stagger = static_cast<size_t>(std::atol(e)) & ~static_cast<size_t>(255);
   if (const char* e = std::getenv("BCG_RING_CHUNK")) c->ring_chunk_override = std::atoi(e);
   if (const char* e = std::getenv("BCG_DEBUG_FIELD_BUDGET")) c->debug_field_budget = static_cast<size_t>(std::atoll(e));
   if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);
@@ -377,7 +376,6 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_HALF_CHUNK_FORCE")) c->half_chunk_force = std::atoi(e) != 0;
   if (const char* e = std::getenv("BCG_HALF_CHUNK")) c->half_chunk_override = std::atoi(e);  // x3 chunk of the half-volume sweep (tests, tuning)
   if (const char* e = std::getenv("BCG_FORCE_TILE_CLASSES")) c->force_tile_classes = std::atoi(e) != 0;
-  if (const char* e = std::getenv("BCG_HOP_FLAGS")) c->hop_tune.nontemporal = (std::atoi(e) & 1) != 0;
   if (const char* e = std::getenv("BCG_HOP_PATCH")) std::sscanf(e, "%d,%d,%d", &c->hop_tune.patch[0], &c->hop_tune.patch[1], &c->hop_tune.patch[2]);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
@@ -645,20 +643,18 @@ int create_field(bcg_context* c, int m, int parity, bcg_field** out) {
       if (c->lat.L[mu] % 2 != 0) BCG_FAIL(c, BCG_ERR_UNSUPPORTED, "half-volume fields: every lattice extent must be even");
   }
   bcg_field* f = new bcg_field{c, m, nullptr, nullptr, parity, parity >= 0 ? c->lat.V / 2 : c->lat.V};
-  // Fields of the lattices that matter have power-of-two sizes (64^4 sites x 768 B = 12 GiB), allocated back to back, so the
-  // streaming kernels read the same offset of up to nine of them at once with identical low address bits.  A per-field
-  // stagger (a multiple of 256 B, so alignment is kept) spreads those accesses over the memory channels.
-  const size_t lead = c->field_stagger * static_cast<size_t>(c->fields_created % 16);
+  // (Fields of the lattices that matter have power-of-two sizes -- 64^4 sites x 768 B = 12 GiB -- and come back to back from
+  //  the driver; a per-field stagger of the virtual addresses was tried against the placement sensitivity of the streaming
+  //  kernels and made it worse on average: profiles/r04_phaseC_placement.txt.  Fields are plain allocations.)
   hipError_t e = (c->debug_field_budget && c->field_bytes_live + field_bytes(f) > c->debug_field_budget)
                      ? hipErrorOutOfMemory  // test aid: a deterministic stand-in for a full device (tests/test_robustness.py)
-                     : hipMalloc(&f->base, field_bytes(f) + c->field_stagger * 16);
+                     : hipMalloc(&f->base, field_bytes(f));
   if (e != hipSuccess) {
     delete f;
     c->err = std::string("bcg_field_create: hipMalloc: ") + hipGetErrorString(e);
     return BCG_ERR_HIP;
   }
-  f->d = reinterpret_cast<double2*>(static_cast<char*>(f->base) + lead);
-  c->fields_created += 1;
+  f->d = static_cast<double2*>(f->base);
   c->field_bytes_live += field_bytes(f);
   *out = f;
   return BCG_OK;

@@ -675,11 +675,7 @@ int bcg_gauge_create(bcg_context* c, bcg_gauge** out) {
   if (!c || !out) return BCG_ERR_INVALID;
   bcg_gauge* g = new bcg_gauge{c, nullptr, nullptr, false};
   const size_t u_bytes = static_cast<size_t>(c->lat.V) * c->ndim * 9 * sizeof(double2);
-  // experiment switch: links in memory the L2 does not cache (they are streamed; the L2 is for the field slices)
-  const char* unc = std::getenv("BCG_U_UNCACHED");
-  hipError_t e = (unc && std::atoi(unc) != 0)
-                     ? hipExtMallocWithFlags(reinterpret_cast<void**>(&g->U), u_bytes, hipDeviceMallocUncached)
-                     : hipMalloc(&g->U, u_bytes);
+  hipError_t e = hipMalloc(&g->U, u_bytes);
   if (e == hipSuccess && c->ghost_sites > 0) e = hipMalloc(&g->Ughost, static_cast<size_t>(c->ghost_sites) * 9 * sizeof(double2));
   if (e != hipSuccess) {
     if (g->U) (void)hipFree(g->U);

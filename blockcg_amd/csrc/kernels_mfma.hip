@@ -108,8 +108,8 @@ struct ShiftPtrs {
 // 32 VGPRs, the prefetch would push the kernel to one wave per SIMD, and one launch takes a single shift anyway.
 // NW: waves per block.  At m = 32 a coefficient matrix is 16.6 KB of LDS; one block of 8 waves per CU (instead of two
 // of 4) shares 9 matrices -- Rinv and four shifts -- so that 8 shifts are two launches and Q is read twice, not five times.
-template <int M, bool PREFETCH, int NW = 4, bool LIN = false>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(LIN ? 4 : 1)))  // LIN: two 8-wave blocks per CU
+template <int M, bool PREFETCH, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1)))
 k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
                                                     const double2* __restrict__ mats, int apply_rinv) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -122,25 +122,13 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
   for (int k = 0; k < nmat; ++k) stage_matrix<M>(smem + k * MD, mats + static_cast<int64_t>(k + off) * M * M, tid, NW * 64);
   __syncthreads();
   const double* const smat = smem - off * MD;  // slot of mats[i] = smat + i * MD
-  // LIN: tiles move as contiguous memory and change ownership through this wave's LDS buffer (tile_load_lin ...)
-  double* const tw = smem + nmat * MD + wave * 16 * (2 * M + 2);
   const int r = lane & 15, kq = lane >> 4;
   const int64_t ntiles = (rows + 15) / 16;
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
     const int64_t row = tile * 16 + r;
     const bool ok = BCG_ROW_OK(row, rows);
-    auto load = [&](Tile<M>& t, const double2* f) __attribute__((always_inline)) {
-      if (LIN) tile_load_lin<M>(t, f, tile, rows, lane);
-      else tile_load<M>(t, f, row, kq, ok);
-    };
-    auto store = [&](Tile<M>& t, double2* f) __attribute__((always_inline)) {  // t is left in the stored layout
-      if (LIN) {
-        mfma_to_lin<M>(t, tw, lane);
-        tile_store_lin<M>(t, f, tile, rows, lane);
-      } else {
-        tile_store<M>(t, f, row, kq, ok);
-      }
-    };
+    auto load = [&](Tile<M>& t, const double2* f) __attribute__((always_inline)) { tile_load<M>(t, f, row, kq, ok); };
+    auto store = [&](Tile<M>& t, double2* f) __attribute__((always_inline)) { tile_store<M>(t, f, row, kq, ok); };
     Tile<M> q;
     load(q, Q);
     Tile<M> p, x;
@@ -148,7 +136,6 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
       load(p, sp.P[0]);
       load(x, sp.X[0]);
     }
-    if (LIN) lin_to_mfma<M>(q, tw, lane);
     if (apply_rinv) {
       Acc<M> A;
       acc_zero<M>(A);
@@ -164,10 +151,6 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
       if (PREFETCH && s + 1 < nshift) {  // prefetch the next shift's tiles while this one computes
         load(pn, sp.P[s + 1]);
         load(xn, sp.X[s + 1]);
-      }
-      if (LIN) {
-        lin_to_mfma<M>(p, tw, lane);
-        lin_to_mfma<M>(x, tw, lane);
       }
       Acc<M> AX, AP;
       acc_from_tile<M>(AX, x);
@@ -537,21 +520,11 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
     hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
   } else if (m == 16) {
     constexpr int M = 16;
-    // contiguous tile moves (LIN, BCG_PHASEC_LIN=1): 8-wave blocks, so that the 9 matrices (38 KB) are shared by eight
-    // per-wave ownership buffers (34.8 KB) and two blocks = 16 waves still fit a CU (145.6 KB).  Off by default: a copy
-    // kernel loses 17 % to the 64-byte-piece shape (tools/microbench/access_shape.hip) but phase C does not -- 38.85 ms
-    // with contiguous moves, 38.88 without, alternating runs on one device (profiles/r03_contiguous_tile_moves.txt).
-    static const bool lin = std::getenv("BCG_PHASEC_LIN") != nullptr && std::atoi(std::getenv("BCG_PHASEC_LIN")) != 0;
-    if (lin) {
-      const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * nmat + 8 * 16 * (2 * M + 2));
-      const int grid8 = grid_tiles((rows + 15) / 16, 8, max_blocks / 2 > 0 ? max_blocks / 2 : 1);
-      allow_lds(k_phaseC<M, true, 8, true>, lds);
-      hipLaunchKernelGGL((k_phaseC<M, true, 8, true>), dim3(grid8), dim3(512), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
-    } else {
-      const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
-      allow_lds(k_phaseC<M, true>, lds);
-      hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
-    }
+    // (contiguous tile moves through a per-wave LDS buffer -- round 3's BCG_PHASEC_LIN -- and through the matrix pipe -- round 5,
+    //  profiles/r05_phaseC_p0.txt -- measured no gain in the row kernels and are gone: the access shape does not bound them)
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
+    allow_lds(k_phaseC<M, true>, lds);
+    hipLaunchKernelGGL((k_phaseC<M, true>), dim3(grid), dim3(256), lds, s, rows, Q, sp, nshift, mats, apply_rinv);
   } else {
     constexpr int M = 32;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * nmat;
@@ -568,20 +541,15 @@ void launch_phaseC(hipStream_t s, int m, int64_t rows, double2* Q, double2* cons
 
 void launch_phaseC_p0(hipStream_t s, int m, int64_t rows, const double2* Q, const double2* P, double2* Pout, const double2* mats,
                       int max_blocks) {
-  // Defaults from profiles/r05_phaseC_p0.txt (64^4, m = 16): the next tile's loads in flight during the products and two
-  // blocks per CU, 7.26 ms per launch; without the prefetch 7.56-7.63 ms at 1024, 1536 or 2048 blocks, with it at 1024 blocks
-  // 7.84.  BCG_P0_AHEAD / BCG_P0_BLOCKS: the knobs of that experiment.
-  static const int ahead = std::getenv("BCG_P0_AHEAD") ? std::atoi(std::getenv("BCG_P0_AHEAD")) : 1;
-  static const int blocks = std::getenv("BCG_P0_BLOCKS") ? std::atoi(std::getenv("BCG_P0_BLOCKS")) : 512;
-  const int grid = grid_tiles((rows + 15) / 16, 4, blocks > 0 && blocks < max_blocks ? blocks : max_blocks);
+  // profiles/r05_phaseC_p0.txt (64^4, m = 16): the next tile's loads in flight during the products and two blocks per CU,
+  // 7.26 ms per launch; without the prefetch 7.56-7.63 ms at 1024, 1536 or 2048 blocks, with it at 1024 blocks 7.84
+  const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks < 512 ? max_blocks : 512);
   if (m == 8) {
     const size_t lds = sizeof(double) * ((MatLds<8>::DOUBLES + 1) & ~1) * 2;
-    if (ahead) hipLaunchKernelGGL((k_phaseC_p0<8, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
-    else hipLaunchKernelGGL((k_phaseC_p0<8, false>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+    hipLaunchKernelGGL((k_phaseC_p0<8, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
   } else {
     const size_t lds = sizeof(double) * ((MatLds<16>::DOUBLES + 1) & ~1) * 2;
-    if (ahead) hipLaunchKernelGGL((k_phaseC_p0<16, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
-    else hipLaunchKernelGGL((k_phaseC_p0<16, false>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
+    hipLaunchKernelGGL((k_phaseC_p0<16, true>), dim3(grid), dim3(256), lds, s, rows, Q, P, Pout, mats);
   }
 }
 

@@ -87,56 +87,6 @@ __device__ __forceinline__ void tile_store(const Tile<M>& t, double2* __restrict
 #endif
 
 
-// ---- the same tile moved as CONTIGUOUS memory ----------------------------------------------------------------------
-// The MFMA ownership above makes every load / store instruction of a wave 16 separate 64-byte pieces (one per row).  A
-// copy kernel with that shape reaches 5.2 TB/s on nine streams where 1 KB-contiguous instructions reach 6.3
-// (tools/microbench/access_shape.hip, profiles/r03_access_shape_microbench.txt).  So the row kernels move a tile as the
-// 16 M contiguous elements it is -- instruction k of M / 4: element e = lane + 64 k, i.e. row e / M, column e % M -- and
-// change ownership through a per-wave LDS buffer of 16 rows x (16 M + 16) bytes (the padding makes both sides
-// conflict-free); the same wave writes and reads it, so LDS ordering suffices.
-template <int M>
-__device__ __forceinline__ void tile_load_lin(Tile<M>& c, const double2* __restrict__ f, int64_t tile, int64_t rows, int lane) {
-  const double2* p = f + tile * (16 * M);
-#pragma unroll
-  for (int k = 0; k < M / 4; ++k) {
-    const int e = lane + 64 * k;
-    c.v[k] = tile * 16 + e / M < rows ? p[e] : make_double2(0.0, 0.0);
-  }
-}
-template <int M>
-__device__ __forceinline__ void tile_store_lin(const Tile<M>& c, double2* __restrict__ f, int64_t tile, int64_t rows, int lane) {
-  double2* p = f + tile * (16 * M);
-#pragma unroll
-  for (int k = 0; k < M / 4; ++k) {
-    const int e = lane + 64 * k;
-    if (tile * 16 + e / M < rows) p[e] = c.v[k];
-  }
-}
-template <int M>
-__device__ __forceinline__ void lin_to_mfma(Tile<M>& t, double* tw, int lane) {
-  constexpr int TLD = 2 * M + 2;
-#pragma unroll
-  for (int k = 0; k < M / 4; ++k) {
-    const int e = lane + 64 * k;
-    *reinterpret_cast<double2*>(tw + (e / M) * TLD + 2 * (e % M)) = t.v[k];
-  }
-  const int r = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int s = 0; s < M / 4; ++s) t.v[s] = *reinterpret_cast<const double2*>(tw + r * TLD + 2 * (4 * s + kq));
-}
-template <int M>
-__device__ __forceinline__ void mfma_to_lin(Tile<M>& t, double* tw, int lane) {
-  constexpr int TLD = 2 * M + 2;
-  const int r = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int s = 0; s < M / 4; ++s) *reinterpret_cast<double2*>(tw + r * TLD + 2 * (4 * s + kq)) = t.v[s];
-#pragma unroll
-  for (int k = 0; k < M / 4; ++k) {
-    const int e = lane + 64 * k;
-    t.v[k] = *reinterpret_cast<const double2*>(tw + (e / M) * TLD + 2 * (e % M));
-  }
-}
-
 // accumulator fragments <-> tile.  Output element (s_o, ri_o) of the lane sits in acc[q>>2][q&3],
 // q = ri_o*(M/4) + s_o.
 template <int M>
