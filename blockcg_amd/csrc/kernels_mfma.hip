@@ -282,6 +282,8 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       tile_load<M>(p, sp.P[0], row, kq, ok);
       tile_load<M>(x, sp.X[0], row, kq, ok);
     }
+    Tile<M> p1;  // XACC: the group's first P_0, in flight while the residual blocks are normalised
+    if (NORM && steps.xacc > 0) tile_load<M>(p1, steps.p1, row, kq, ok);
     if (NORM) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
@@ -293,8 +295,6 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
     }
     const double* mat = smem + (NORM ? NS : 0) * MD;
     if (NORM && steps.xacc > 0) {  // wave-uniform: the deferred X_0 updates of the group's earlier iterations
-      Tile<M> p1;
-      tile_load<M>(p1, steps.p1, row, kq, ok);
       const double* cm = mat + 2 * (steps.last[0] - steps.first[0]) * MD;
       Acc<M> AX;
       acc_from_tile<M>(AX, x);
