@@ -68,7 +68,7 @@ struct bcg_context {
   size_t halo_bytes = 0;
   void* halo_save = nullptr;             // capacity mode, overlapped exchanges: the source's received faces of slice x3 = 0
   size_t halo_save_bytes = 0;
-  int lazy_q = 1;                        // SBCGrQ: deferred normalisation of Q (phase_B in blockcg_capi.hip; BCG_LAZY_Q)
+  int lazy_q = 1;                        // SBCGrQ: deferred normalisation of Q (phase_B in capi_solvers.hip; BCG_LAZY_Q)
   int pair_shifts = 4;                   // SBCGrQ: shifts >= 1 updated this many iterations at a time (pair_shifts_depth; BCG_PAIR_SHIFTS)
   bool defer_x0 = true;                  // SBCGrQ: X_0's updates wait for the pass that closes a group too (DeferredX0; BCG_DEFER_X0)
   size_t debug_field_budget = 0;         // test aid (BCG_DEBUG_FIELD_BUDGET, bytes): field allocations beyond it fail like an out-of-memory

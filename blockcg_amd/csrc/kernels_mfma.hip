@@ -28,7 +28,7 @@ namespace {
 // Phase B:  Q -= T*alpha  (matrix passed as -alpha),  accumulate Q^dagger Q of the NEW Q.
 // ---------------------------------------------------------------------------------------------------
 template <int M>
-// rinv != nullptr (deferred normalisation, see phase_B in blockcg_capi.hip): the stored Q is the previous iteration's
+// rinv != nullptr (deferred normalisation, see phase_B in capi_solvers.hip): the stored Q is the previous iteration's
 // un-normalised block; it is multiplied by rinv = rho_prev^-1 first -- the arithmetic phase C used to do before storing it.
 // Qout: where the new Q goes (== Q: in place; another buffer when the old block must survive, see k_phaseC_multi; that
 // buffer may be T itself: every wave has read its tile of T when it writes that tile, and no other wave touches it).
@@ -173,7 +173,7 @@ k_phaseC(int64_t rows, double2* __restrict__ Q, ShiftPtrs sp, int nshift,
   }
 }
 
-// Phase C of shift 0 with the update of X_0 DEFERRED (SBCGrQ, defer_x0 in blockcg_capi.hip):  q = Q rinv (in registers, not
+// Phase C of shift 0 with the update of X_0 DEFERRED (SBCGrQ, DeferredX0 in capi_solvers.hip):  q = Q rinv (in registers, not
 // stored);  Pout = P B + q.  X_0 is not touched -- the pass that closes the group of iterations adds the group's updates to
 // it at once (k_phaseC_multi, XACC) -- so this pass moves three fields instead of five.  Pout may be P (in place: a wave
 // reads its tile before it writes it) or another buffer (the first iteration of a group: the group's first P_0 must

@@ -1,6 +1,6 @@
 // blockcg/standard_solvers.hpp -- drop-in for the reference's inc/standard_solvers.hpp (CG, SCG) on MI355X.
 // Same signatures (inc/standard_solvers.hpp:10-11,18-20); the loops run in libblockcg_hip.so on the
-// width-1 kernels (src/standard_solvers.cpp:3-95 restated in blockcg_amd/csrc/blockcg_capi.hip).
+// width-1 kernels (src/standard_solvers.cpp:3-95 restated in blockcg_amd/csrc/capi_solvers.hip).
 #ifndef BLOCKCG_STANDARD_SOLVERS_HPP
 #define BLOCKCG_STANDARD_SOLVERS_HPP
 #include "dirac_op.hpp"

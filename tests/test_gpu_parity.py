@@ -750,7 +750,7 @@ def test_fused_true_residual_check(bc, orc, monkeypatch):
 @pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
 def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypatch):
     """Phase C keeps Q rho^-1 in registers and leaves the un-normalised Q in memory; the next phase B applies the same
-    rho^-1 with the same kernel arithmetic (blockcg_capi.hip: lazy_q_width): the iterates must equal, bit for bit, those of
+    rho^-1 with the same kernel arithmetic (capi_solvers.hip: lazy_q_width): the iterates must equal, bit for bit, those of
     the form that stores Q rho^-1 and reads it back (BCG_LAZY_Q=0), and match the oracle."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
     monkeypatch.setenv("BCG_PAIR_SHIFTS", "0")  # the paired updates build on this and have their own test below
@@ -784,11 +784,11 @@ def test_deferred_normalisation_of_q_is_bit_identical(bc, orc, m, dims, monkeypa
                          ids=["m16-2", "m16-3", "m16-4", "m8-2", "m8-3", "m8-4", "m32-2"])
 @pytest.mark.parametrize("defer_x0", [0, 1], ids=["x0-every-iteration", "x0-deferred"])
 def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, defer_x0, monkeypatch):
-    """The shifts >= 1 are updated `depth` iterations at a time (blockcg_capi.hip: pair_shifts_depth, k_phaseC_multi).
+    """The shifts >= 1 are updated `depth` iterations at a time (capi_solvers.hip: pair_shifts_depth, k_phaseC_multi).
     After any number of iterations -- a multiple of the depth or not, run in one call or in pieces, with shifts leaving the
     active set on the way -- X and the residual must equal, bit for bit, those of the solver that updates every shift in
     every iteration (BCG_PAIR_SHIFTS=0), and match the oracle.
-    x0-deferred (the default at m = 8, 16: DeferredX0 in blockcg_capi.hip): X_0's updates wait for the closing pass as
+    x0-deferred (the default at m = 8, 16: DeferredX0 in capi_solvers.hip): X_0's updates wait for the closing pass as
     well, composed onto the group's first P_0 -- the P_0 sequence, the residual, every X_s with s >= 1 stay bit-identical,
     X_0 agrees to rounding (1e-13), and a group moves 3 (g - 1) + g + 4 S + 1 field passes."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")

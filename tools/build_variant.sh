@@ -9,5 +9,5 @@ mkdir -p /tmp/bcg_variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c kernels_stencil.hip -o /tmp/bcg_variants/ks_$name.o &
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c kernels_mfma.hip -o /tmp/bcg_variants/km_$name.o &
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../_build/libblockcg_hip_$name.so ../_build/blockcg_capi.o ../_build/kernels_generic.o /tmp/bcg_variants/km_$name.o /tmp/bcg_variants/ks_$name.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../_build/libblockcg_hip_$name.so ../_build/capi_context.o ../_build/capi_operator.o ../_build/capi_solvers.o ../_build/kernels_generic.o /tmp/bcg_variants/km_$name.o /tmp/bcg_variants/ks_$name.o
 echo built $name
