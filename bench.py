@@ -262,7 +262,12 @@ def rung_plan(lib, rung, world, m, S):
     iv = lambda v: (ctypes.c_int * 4)(*(list(v) + [1] * (4 - len(v))))  # noqa: E731
     overlapped = bool(cap >= 4 and world > 1)  # every transport offers the split callbacks
     chunk = ((cap - 2) // 2 if overlapped else cap - 2) if cap else 0
-    depth = 1 if S < 2 or m not in (8, 16, 32) else (2 if (cap or m == 32) else 4)
+    if m not in (8, 16, 32):
+        depth = 1
+    elif S < 2:  # a single system groups for the deferred X_0 update's sake alone (m = 8, 16 outside capacity mode)
+        depth = 4 if (m in (8, 16) and not cap) else 1
+    else:
+        depth = 2 if (cap or m == 32) else 4
     planned = ctypes.c_size_t()
     rc = lib.bcg_sbcgrq_plan_bytes(ndim, iv(gdims), iv(grid), m, S, 1, cap, 1 if overlapped else 0, depth, ctypes.byref(planned))
     if rc != 0:

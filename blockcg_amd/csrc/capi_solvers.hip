@@ -107,11 +107,18 @@ int phase_C(bcg_context* c, bcg_field* Q, const CMat& rho, bcg_field* const* X, 
 // residual buffers the group releases becomes the next T.  So D = 2 costs no memory at all and is what capacity mode
 // runs.  BCG_PAIR_SHIFTS=<depth> (0 or 1: off; default 4, the largest instantiated).  Measured at 64^4,
 // m = 16, 4 shifts: 67.0 ms per iteration without, 55.5-56.1 at depth 2, 54.3 at 3, 53.4-53.7 at 4 (profiles/r03_group_depth.txt).
+// A single system (n_shifts = 1) has no shifted updates to group, but where X_0's update can wait (x0_may_wait, DeferredX0
+// below) a group of three or four iterations still saves field passes: 3 s for each iteration inside it and 9 s for the
+// closing one, against 5 s each.  A group of two would save nothing (3 + 7), so there it is depth >= 3 or none.
+bool x0_may_wait(const bcg_context* c, int m) {
+  return c->defer_x0 && lazy_q_width(c, m) && (m == 8 || m == 16) && !capacity_path(c, m);
+}
 int pair_shifts_depth(const bcg_context* c, int m, int n_shifts) {
-  if (c->pair_shifts < 2 || n_shifts < 2 || !fast_rows(c, m) || !fast_rmul(c, m)) return 1;
+  if (c->pair_shifts < 2 || !fast_rows(c, m) || !fast_rmul(c, m)) return 1;
   if (!lazy_q_width(c, m) && m != 32) return 1;  // m = 8, 16 group the un-normalised blocks; m = 32 the stored ones, in pairs
   int d = std::min(c->pair_shifts, capacity_path(c, m) ? 2 : 4);
   while (d >= 2 && !bcg::phaseC_multi_fits(m, d, n_shifts)) --d;
+  if (n_shifts < 2 && (d < 3 || !x0_may_wait(c, m))) return 1;
   return d;
 }
 
@@ -644,10 +651,14 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   }
   const bool lazy = lazy_q_width(c, m);
   const bool next_certain = more_follow && st->residual > st->eps;
-  if (static_cast<int>(st->pending.size()) + 1 < st->depth && next_certain && n_active >= 2) {
+  const bool group_open = static_cast<int>(st->pending.size()) + 1 < st->depth && next_certain;
+  const bool x0_waits = group_open && st->defer_x0 && lazy &&
+                        (st->pending.empty() ? st->P0_spare != nullptr : st->pending[0].x0_deferred);
+  // (with shift 0 alone left -- a single system, or the tail of a solve whose shifted systems have converged -- a group
+  // is worth opening only for X_0's sake, and only if it can run to three iterations: pair_shifts_depth)
+  if (group_open && (n_active >= 2 || (x0_waits && st->depth >= 3))) {
     // shift 0 now, the others in a later iteration's pass (phase_C_multi)
     DeferredIteration d;
-    const bool x0_waits = st->defer_x0 && lazy && (st->pending.empty() ? st->P0_spare != nullptr : st->pending[0].x0_deferred);
     if (x0_waits) {
       // P_0 alone (k_phaseC_p0): the first iteration of a group leaves its P_0 where it is and writes the new one into
       // the spare field; the later ones update in place.  X_0's update joins the closing pass (DeferredX0).
@@ -864,7 +875,7 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
     st->Qfree.push_back(q);
   }
   // deferred X_0 (DeferredX0): one more field, optional like the residual buffers
-  if (st->depth >= 2 && c->defer_x0 && lazy_q_width(c, m) && (m == 8 || m == 16) && !capacity_path(c, m)) {
+  if (st->depth >= 2 && x0_may_wait(c, m)) {
     if (create_like(c, B, &st->P0_spare) == BCG_OK) {
       st->defer_x0 = true;
     } else {
@@ -872,6 +883,14 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
       c->err.clear();
       st->P0_spare = nullptr;
     }
+  }
+  if (n_shifts < 2 && (st->depth < 3 || !st->defer_x0)) {  // a single system groups for X_0's sake or not at all
+    for (bcg_field* q : st->Qfree) bcg_field_destroy(q);
+    st->Qfree.clear();
+    if (st->P0_spare) bcg_field_destroy(st->P0_spare);
+    st->P0_spare = nullptr;
+    st->defer_x0 = false;
+    st->depth = 1;
   }
   st->iter = 0;                            // :126
   st->b_norm = st->delta.row_norms();      // :130

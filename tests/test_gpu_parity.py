@@ -848,6 +848,69 @@ def test_grouped_shift_updates_are_bit_identical(bc, orc, m, dims, depth, defer_
         assert rel_err(a[s], o["X"][s]) < 1e-10
 
 
+@pytest.mark.parametrize("m,dims", [(16, [16, 8, 8, 8]), (8, [16, 8, 4, 8])], ids=["m16", "m8"])
+def test_single_system_groups_for_the_deferred_x0_update(bc, orc, m, dims, monkeypatch):
+    """With shift 0 alone -- a one-shift solve, or the tail of a solve whose shifted systems have converged -- there are no
+    shifted updates to group, but X_0's can still wait (DeferredX0): groups of three or four iterations move 3 s inside and
+    q_0..q_{g-1}, P_0, X_0, the group's first P_0 read + P_0, X_0 written in the closing pass, against 5 s per iteration
+    (capi_solvers.hip: pair_shifts_depth, x0_may_wait).  A group of two would save nothing and is not opened.  Residual and
+    P_0 sequence bit-identical to the plain solver, X_0 to rounding; the oracle agrees."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    mass = 0.2
+    U = orc.fill_gauge(dims, 63)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 64)
+
+    def run(shifts, pair, defer, pieces, eps_shifts=0.0):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+        monkeypatch.setenv("BCG_DEFER_X0", str(defer))
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, eps_shifts)
+        for n in pieces:
+            st.iterate(n)
+        res, planned = st.residual, ctx.sbcgrq_device_bytes(m, len(shifts))
+        st.end()
+        return [x.download() for x in X], res, ctx.profile(), planned
+
+    field = int(np.prod(dims)) * 3 * m * 16
+    b, rb, pb, mem_plain = run([0.0], 0, 1, [12])
+    assert set(k for k in pb if k.startswith("phaseC")) == {"phaseC"}
+    per_pass = pb["phaseC"]["bytes"] / (12 * 5)
+    for depth, pieces in ((4, [12]), (3, [12]), (4, [7]), (4, [2, 3, 1, 4, 5]), (4, [1, 1, 1])):
+        a, ra, pa, mem = run([0.0], depth, 1, pieces)
+        ref, rref, _, _ = (b, rb, pb, 0) if sum(pieces) == 12 else run([0.0], 0, 1, pieces)
+        assert ra == rref and rel_err(a[0], ref[0]) < 1e-13, (depth, pieces)
+        assert mem == mem_plain + (depth - 2 + 1) * field  # the further residual buffers and the spare P_0
+        groups = [g for n in pieces for g in [depth] * (n // depth) + [n % depth] if g > 0]
+        for g in (2, 3, 4):
+            assert pa.get(f"phaseC_multi{g}", {}).get("count", 0) == groups.count(g), (depth, pieces, g)
+        assert pa.get("phaseC_p0", {}).get("count", 0) == sum(g - 1 for g in groups)
+        moved = sum(v["bytes"] for k, v in pa.items() if k.startswith("phaseC"))
+        assert moved == pytest.approx(per_pass * sum(3 * (g - 1) + g + 5 if g >= 2 else 5 for g in groups), rel=1e-9)
+    # no group of two, and none without the deferred update: the plain kernel in every iteration, bit-identical
+    for pair, defer in ((2, 1), (4, 0)):
+        a, ra, pa, mem = run([0.0], pair, defer, [12])
+        assert ra == rb and np.array_equal(a[0], b[0]) and mem == mem_plain
+        assert set(k for k in pa if k.startswith("phaseC")) == {"phaseC"}
+    o = orc.sbcgrq(U, dims, mass, Bh, [0.0], 0.0, 0.0, max_iterations=12)
+    a, _, _, _ = run([0.0], 4, 1, [12])
+    assert rel_err(a[0], o["X"][0]) < 1e-10
+    # the tail of a two-shift solve: the shifted system leaves the active set early, the groups go on for X_0's sake
+    shifts = [0.0, 2.0]
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.5, max_iterations=12, trace_limit=12)
+    visited = o["trace"]["residual_shift"][:, 1] >= 0.0
+    assert visited[0] and not visited[4:].any()
+    a, ra, pa, _ = run(shifts, 4, 1, [12], 0.5)
+    c, rc, pc, _ = run(shifts, 0, 1, [12], 0.5)
+    assert ra == rc and np.array_equal(a[1], c[1]) and rel_err(a[0], c[0]) < 1e-13
+    assert pa["phaseC_multi4"]["count"] == 3 and pa["phaseC_p0"]["count"] == 9 and "phaseC" not in pa
+    for s in range(2):
+        assert rel_err(a[s], o["X"][s]) < 1e-10
+
+
 @pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 4), (8, [32, 4, 4, 8], 4)], ids=["m16", "m8"])
 def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypatch):
     """Capacity mode groups the shift updates over two iterations: that depth needs no memory (the phase B that closes a
