@@ -175,7 +175,14 @@ def launch_ranks(args, argv):
 def apply_config(args, world):
     """--config 4: the declared stand-in shape of BASELINE configs[4] (m = 32, 8 shifts; 128^4 at that width needs 8 TB): the
     largest volume that fits 288 GB per GPU, 64^3 x 32 sites (19 fields of 12.9 GB + links = 250 GB), i.e. 128^3 x 32 on 8 GPUs.
+    --config 1: BASELINE configs[1] (32^4, m = 8, 1 shift, one GPU).
     --config 2 / 3 are the defaults at N = 1 / N > 1 and change nothing."""
+    if args.config == 1:
+        if world != 1:
+            sys.exit("--config 1 is a one-GPU configuration (32^4, m = 8, 1 shift)")
+        args.m, args.shifts = 8, 1
+        if args.local_dims is None:
+            args.local_dims = [32, 32, 32, 32]
     if args.config == 4:
         args.m, args.shifts = 32, 8
         if args.local_dims is None:
@@ -485,8 +492,8 @@ def main():
                     help="sites per GPU (default: 64 64 64 64 on one GPU, 64 64 64 128 on several)")
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--shifts", type=int, default=4)
-    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4],
-                    help="a BASELINE.json configuration by number: 2 = 64^4, m=16, 4 shifts on one GPU (the default at N=1); "
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="a BASELINE.json configuration by number: 1 = 32^4, m=8, 1 shift on one GPU; 2 = 64^4, m=16, 4 shifts on one GPU (the default at N=1); "
                          "3 = the 128^4 ladder (the default at N>1); 4 = the wide-block stress, m=32 and 8 shifts, on the "
                          "largest volume that fits: 64^3 x 32 sites per GPU (19 fields of 12.9 GB + links = 250 GB; the "
                          "BASELINE's 128^4 would need 8 TB), i.e. 128^3 x 32 on 8 GPUs")

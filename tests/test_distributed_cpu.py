@@ -85,3 +85,8 @@ def test_bench_config_4_is_the_declared_wide_block_shape():
     assert grid_for(8, 4, keep_last=True) == [2, 2, 2, 1]
     b = bench.apply_config(argparse.Namespace(config=None, m=16, shifts=4, local_dims=None, capacity=None), 1)
     assert (b.m, b.shifts, b.local_dims) == (16, 4, None)
+    # --config 1: BASELINE configs[1] (32^4, m = 8, 1 shift), one GPU only
+    c1 = bench.apply_config(argparse.Namespace(config=1, m=16, shifts=4, local_dims=None, capacity=None), 1)
+    assert (c1.m, c1.shifts, c1.local_dims) == (8, 1, [32, 32, 32, 32])
+    with pytest.raises(SystemExit):
+        bench.apply_config(argparse.Namespace(config=1, m=16, shifts=4, local_dims=None, capacity=None), 8)
