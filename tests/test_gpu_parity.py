@@ -911,6 +911,53 @@ def test_single_system_groups_for_the_deferred_x0_update(bc, orc, m, dims, monke
         assert rel_err(a[s], o["X"][s]) < 1e-10
 
 
+def test_grouping_randomised_schedules(bc, orc, monkeypatch):
+    """Seeded random schedules through the solver's state machine: width 8 / 16, 1 ... 8 shifts of random size (so that some
+    retire early, some never), group depth 2 ... 4, X_0 deferred or not, the iterations asked for in random pieces (a piece
+    of one iteration closes a group at once; a short piece leaves a partial group).  Whatever the schedule, the residual
+    and every X_s with s >= 1 equal the plain solver's bit for bit, X_0 to rounding, and the oracle agrees."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    rng = np.random.default_rng(20261005)
+    mass = 0.25
+    for case in range(40):
+        m = int(rng.choice([8, 16]))
+        dims = [16, 8, 4, 8] if m == 8 else [16, 4, 4, 8]
+        S = int(rng.choice([1, 1, 2, 3, 4, 5, 8]))
+        shifts = [0.0] + sorted(float(x) for x in rng.choice([1e-4, 1e-2, 0.05, 0.3, 0.8, 1.5, 3.0, 6.0, 12.0], size=S - 1, replace=False))
+        depth, defer = int(rng.integers(2, 5)), int(rng.integers(0, 2))
+        eps_shifts = float(rng.choice([0.0, 1e-3, 3e-2, 0.3]))
+        pieces = [int(x) for x in rng.integers(1, 7, size=int(rng.integers(1, 5)))]
+        U = orc.fill_gauge(dims, 200 + case)
+        Bh = orc.fill_field(m, int(np.prod(dims)), 300 + case)
+
+        def run(pair):
+            monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+            monkeypatch.setenv("BCG_DEFER_X0", str(defer))
+            ctx = bc.Context(dims)
+            D = bc.dirac_op(ctx, mass, U=U)
+            B = bc.block_fermion_field(ctx, m, Bh)
+            X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+            st = bc.SBCGrQState(X, B, D, shifts, 0.0, eps_shifts)
+            for n in pieces:
+                st.iterate(n)
+            res, it = st.residual, st.iterations
+            st.end()
+            return [x.download() for x in X], res, it
+
+        what = dict(case=case, m=m, shifts=shifts, depth=depth, defer=defer, eps_shifts=eps_shifts, pieces=pieces)
+        a, ra, ia = run(depth)
+        b, rb, ib = run(0)
+        assert (ra, ia) == (rb, ib) and ia == sum(pieces), what
+        for s in range(S):
+            if s == 0:
+                assert rel_err(a[0], b[0]) < 1e-13, what
+            else:
+                assert np.array_equal(a[s], b[s]), (what, s)
+        o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, eps_shifts, max_iterations=sum(pieces))
+        for s in range(S):
+            assert rel_err(a[s], o["X"][s]) < 1e-10, (what, s)
+
+
 @pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 4), (8, [32, 4, 4, 8], 4)], ids=["m16", "m8"])
 def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypatch):
     """Capacity mode groups the shift updates over two iterations: that depth needs no memory (the phase B that closes a
