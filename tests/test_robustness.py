@@ -115,6 +115,40 @@ def test_error_inside_a_group_leaves_every_shift_current(bc, m, dims, depth, mon
             assert np.abs(a[1]).max() > 0  # the shifted systems did move before the failure
 
 
+@pytest.mark.parametrize("m,dims,depth", [(16, [16, 8, 8, 8], 4), (8, [16, 8, 4, 8], 3)], ids=["m16-4", "m8-3"])
+def test_error_inside_a_group_of_a_single_system(bc, m, dims, depth, monkeypatch):
+    """A single system groups its iterations for the deferred X_0 update alone (pair_shifts_depth, x0_may_wait): a failure
+    inside a group finds nothing to apply for the shifts >= 1 and the composed X_0 updates of 1 .. depth-1 iterations
+    pending.  X_0 must equal the plain solver's at the same failure (to rounding), whatever the position in the group."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    mass = 0.2
+
+    def run(pair, fail_at):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+        monkeypatch.setenv("BCG_DEBUG_FAIL_ITER", str(fail_at))
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, seed=93)
+        B = bc.block_fermion_field(ctx, m).setRandom(seed=94)
+        X = [bc.block_fermion_field(ctx, m)]
+        st = bc.SBCGrQState(X, B, D, [0.0], 0.0, 0.0)
+        with pytest.raises(bc.BlockCGError) as e:
+            st.iterate(12)
+        assert e.value.code == 6  # BCG_ERR_NUMERIC
+        st.end()
+        out, prof = X[0].download(), ctx.profile()
+        ctx.close()
+        return out, prof
+
+    for fail_at in range(1, depth + 3):
+        a, pa = run(depth, fail_at)
+        b, pb = run(0, fail_at)
+        assert np.isfinite(a).all() and rel_err(a, b) < 1e-13, fail_at
+        assert "phaseC_p0" not in pb
+        if fail_at >= 2:  # at least one iteration completed inside a group before the failure
+            assert pa["phaseC_p0"]["count"] >= 1 and np.abs(a).max() > 0
+
+
 def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypatch):
     """bcg_sbcgrq_begin allocates what the operator needs (tmp, scratch) BEFORE the optional residual buffers of the grouped
     shift updates.  With room for the base plan + 1.5 fields the default depth 4 (two extra fields) must fall back to depth 3
