@@ -133,11 +133,14 @@ int bcg_force_generic(bcg_context* ctx, int enable);
 int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
 /* Device memory one SBCGrQ solve of width m with n_shifts shifts occupies on this rank in the current mode: X_s, P_s,
  * Q, T (+ the caller's B unless consume_B), tmp or its ring, links, halo buffers, scratch -- and, outside capacity mode
- * at m = 8 and 16 with two or more shifts, up to two further residual buffers: the solver updates X_s, P_s of the
+ * at m = 8 and 16, up to two further residual buffers and one spare field: the solver updates X_s, P_s of the
  * shifts s >= 1 (inc/block_solvers.hpp:161-181) up to four iterations at a time, which needs the residual block of
- * each deferred iteration (two at a time, as in capacity mode and at m = 32, need none: T doubles as the second buffer).  Results are
- * bit-identical; a solve that cannot allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation
- * switches the grouping off.  Host arithmetic only. */
+ * each deferred iteration (two at a time, as in capacity mode and at m = 32, need none: T doubles as the second buffer),
+ * and X_0 (:145) with them, which needs the group's first P_0 kept in the spare field while P_0 moves on.  A single
+ * system (n_shifts = 1) groups for X_0's sake alone, in threes or fours or not at all.  X_s, s >= 1, the residuals and
+ * the iteration count are bit-identical to the ungrouped solver, X_0 agrees to rounding (1e-13); a solve that cannot
+ * allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation switches the grouping off, BCG_DEFER_X0=0
+ * the deferred X_0 update.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
 /* The same plan without a context or a device, for one rank of a process grid (a launcher sizing a run before it starts
  * its ranks): ring_slices = 0 for a whole `tmp`; ring_overlapped = the per-chunk exchanges overlap (split callbacks
