@@ -130,6 +130,7 @@ struct DeferredIteration {
   std::vector<CMat> A, B;        // their coefficients, by shift
   bool x0_deferred = false;      // its update of X_0 (:145) waits too (DeferredX0 below); then:
   CMat A0, R0;                   //   X_0 += P_0 A0 (A0 = alpha delta_old) was due, and P_0 <- P_0 R0 + q was done (R0 = rho^dagger)
+  bool x0_backward = false;      //   ... and its P_0 was NOT kept: the spare-less form of a group of two (DeferredX0)
 };
 
 // Deferred update of X_0 (m = 8, 16 outside capacity mode; BCG_DEFER_X0=0 switches it off).  X_0 is never read by the
@@ -145,13 +146,23 @@ struct DeferredIteration {
 // The P_0 sequence, hence every coefficient, residual and iteration count, is bit-identical to the undeferred solver; X_0
 // differs by rounding (the composed matrices associate the products differently): tolerance-level, tests/test_gpu_parity.py.
 // Cost: one more field (the spare).  Measured: DESIGN.md section 4.
+// The spare-less form of a group of TWO (capacity mode, whose point is the memory; or a solve that could not allocate the
+// spare): the first iteration updates P_0 in place, and the closing pass -- which holds P_0^(1) and q_0 in registers --
+// gets the lost block back from P_0^(1) = P_0^(0) R_0 + q_0:
+//     P_0^(0) A_0 = (P_0^(1) - q_0) M ,   M = R_0^-1 A_0 = (rho_0^-1)^dagger A_0
+// so X_0 += P_0^(1) (A_1 + M) - q_0 M: the closing step's own coefficient changed on the host and ONE more product, no
+// field read or kept.  R_0^-1 amplifies rounding by the condition of rho_0 -- the triangular factor of the new residual
+// block in the old orthonormal basis, 1.1 .. 1.4 along ordinary solves (it is the block's convergence factor per
+// direction) -- so the form is taken only while ||rho||_F ||rho^-1||_F <= 64 m (condition <= 64 m at worst: rounding
+// below 1e-12 relative); otherwise that iteration runs the plain five-pass update.  One inverse only: longer groups
+// would chain them, and keep the spare.
 struct DeferredX0 {
   std::vector<CMat> mats;  // [C, D_0 .. D_{n-2}]
 };
 DeferredX0 compose_x0(const std::vector<DeferredIteration>& pend) {
   DeferredX0 out;
   const int n = static_cast<int>(pend.size());
-  if (n == 0 || !pend[0].x0_deferred) return out;
+  if (n == 0 || !pend[0].x0_deferred || pend[0].x0_backward) return out;
   const int m = pend[0].A0.dim();
   for (int k = -1; k + 1 < n; ++k) {  // k = -1: the coefficient of P_0^(0); k >= 0: that of q_k
     CMat sum(m), chain = CMat::identity(m);
@@ -207,7 +218,15 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
     }
     entries.push_back(e);
   }
-  const DeferredX0 x0 = (p0_first && lazy && !flush_rinv) ? compose_x0(pend) : DeferredX0();
+  DeferredX0 x0 = (p0_first && lazy && !flush_rinv) ? compose_x0(pend) : DeferredX0();
+  CMat A0_back;  // the closing step's coefficient in the spare-less form: A_1 + M
+  if (!p0_first && lazy && !flush_rinv && ns == 2 && pend[0].x0_deferred && pend[0].x0_backward) {
+    const CMat M = pend[0].rinv.adjoint() * pend[0].A0;  // R_0^-1 A_0, R_0 = rho_0^dagger
+    A0_back = A0 + M;
+    entries[0].mats[0] = &A0_back;
+    x0.mats.push_back(CMat(m));  // the slot of the P_0^(0) term: not read (p1 = nullptr)
+    x0.mats.push_back(-M);       // q_0's coefficient
+  }
   const int xacc = static_cast<int>(x0.mats.size());
   if (xacc > 0) {  // (entry 0 is shift 0's: its step matrices, then the composed ones)
     for (const CMat& M : x0.mats) entries[0].mats.push_back(&M);
@@ -245,9 +264,11 @@ int phase_C_multi(bcg_context* c, const std::vector<DeferredIteration>& pend, bc
     BCG_TRY(upload_mats(c, m, mats.data(), static_cast<int>(mats.size()), &Md));
     {
       // one profile entry per group size: each is its own kernel instantiation (k_phaseC_multi<m, waves, ns>)
-      ProfScope ps(c, names[ns], row_bytes(Qnew, ns + 4 * n + (with_x0 ? 1 : 0)), product_flops(Qnew, products));
+      const double2* const p1 = (with_x0 && p0_first) ? p0_first->d : nullptr;
+      // (the unread slot of the spare-less form is no product)
+      ProfScope ps(c, names[ns], row_bytes(Qnew, ns + 4 * n + (p1 ? 1 : 0)), product_flops(Qnew, products - ((with_x0 && !p1) ? 1 : 0)));
       bcg::launch_phaseC_multi(c->stream, m, rows_of(Qnew), ns, Qd, Xp, Pp, n, first, last, Md, c->row_blocks_C, lazy,
-                               with_x0 ? xacc : 0, with_x0 ? p0_first->d : nullptr);
+                               with_x0 ? xacc : 0, p1);
     }
     BCG_TRY(check_launch(c, "phaseC_multi"));
     e0 += n;
@@ -545,6 +566,7 @@ struct bcg_sbcgrq_state {
   bool defer_x0 = false;                 // the updates of X_0 wait for the pass that closes the group too (DeferredX0)
   bcg_field* P0_spare = nullptr;         // ... the field the first iteration of a group writes its new P_0 into
   bcg_field* P0_first = nullptr;         // ... and, inside a group, the group's first P_0 (P[0] is then the former spare)
+  bool x0_backward = false;              // groups of two without a spare field: the spare-less form (DeferredX0)
   bool failed = false;                   // an iteration returned an error: no further iterations on this state
 };
 
@@ -652,8 +674,20 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
   const bool lazy = lazy_q_width(c, m);
   const bool next_certain = more_follow && st->residual > st->eps;
   const bool group_open = static_cast<int>(st->pending.size()) + 1 < st->depth && next_certain;
-  const bool x0_waits = group_open && st->defer_x0 && lazy &&
-                        (st->pending.empty() ? st->P0_spare != nullptr : st->pending[0].x0_deferred);
+  bool x0_waits = group_open && st->defer_x0 && lazy &&
+                  (st->pending.empty() ? st->P0_spare != nullptr : st->pending[0].x0_deferred);
+  // the spare-less form (a group of two that has no spare field: capacity mode, or the spare could not be allocated)
+  bool x0_backward = false;
+  if (group_open && !x0_waits && st->x0_backward && lazy && st->depth == 2 && st->pending.empty() && n_active >= 2) {
+    const CMat rinv = bcg::upper_triangular_inverse(st->rho);
+    double f2 = 0.0, g2 = 0.0;
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) {
+        f2 += std::norm(st->rho(i, j));
+        g2 += std::norm(rinv(i, j));
+      }
+    x0_backward = x0_waits = std::sqrt(f2 * g2) <= 64.0 * m;  // (NaN compares false: the plain update)
+  }
   // (with shift 0 alone left -- a single system, or the tail of a solve whose shifted systems have converged -- a group
   // is worth opening only for X_0's sake, and only if it can run to three iterations: pair_shifts_depth)
   if (group_open && (n_active >= 2 || (x0_waits && st->depth >= 3))) {
@@ -666,18 +700,19 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
       const CMat* two[2] = {&st->q_rinv, &rho_dag};
       const double2* Md;
       BCG_TRY(upload_mats(c, m, two, 2, &Md));
-      bcg_field* const out = st->pending.empty() ? st->P0_spare : st->P[0];
+      bcg_field* const out = (st->pending.empty() && !x0_backward) ? st->P0_spare : st->P[0];
       {
         ProfScope ps(c, "phaseC_p0", row_bytes(st->Q, 3), product_flops(st->Q, 2));
         bcg::launch_phaseC_p0(c->stream, m, rows_of(st->Q), st->Q->d, st->P[0]->d, out->d, Md, c->row_blocks_C);
       }
       BCG_TRY(check_launch(c, "phaseC_p0"));
-      if (st->pending.empty()) {
+      if (st->pending.empty() && !x0_backward) {
         st->P0_first = st->P[0];
         st->P[0] = st->P0_spare;
         st->P0_spare = nullptr;
       }
       d.x0_deferred = true;
+      d.x0_backward = x0_backward;
       d.A0 = alpha_delta;
       d.R0 = rho_dag;
     } else {
@@ -754,7 +789,13 @@ int sbcgrq_flush_pending(bcg_sbcgrq_state* st) {
   pend.push_back(last);
   // ... and X_0's, where they waited too: X_0 += P_0^(0) C + sum_k Q_k (rinv_k D_k), over ALL pending iterations (no
   // closing iteration follows: the sum over q_k runs to the last but one, the last one's q only entered the current P_0)
-  if (rc == BCG_OK && st->P0_first && pend[0].x0_deferred) {
+  if (rc == BCG_OK && pend[0].x0_deferred && pend[0].x0_backward) {
+    // the spare-less form: one iteration pending, its P_0 gone -- X_0 += (P_0^(1) - q_0) M with the current P_0 (the failed
+    // iteration has not touched it) and M = R_0^-1 A_0
+    const CMat M = pend[0].rinv.adjoint() * pend[0].A0;
+    rc = rmul(c, st->X[0], st->P[0], M, 0.0, bcg::RMUL_ADD, "block_axpy");
+    if (rc == BCG_OK) rc = rmul(c, st->X[0], pend[0].Q, -(pend[0].rinv * M), 0.0, bcg::RMUL_ADD, "block_axpy");
+  } else if (rc == BCG_OK && st->P0_first && pend[0].x0_deferred) {
     const DeferredX0 x0 = compose_x0(pend);
     rc = rmul(c, st->X[0], st->P0_first, x0.mats[0], 0.0, bcg::RMUL_ADD, "block_axpy");
     for (size_t k = 0; k + 1 < x0.mats.size() && rc == BCG_OK; ++k)
@@ -884,6 +925,7 @@ int bcg_sbcgrq_begin(bcg_context* c, const bcg_gauge* g, double mass, bcg_field*
       st->P0_spare = nullptr;
     }
   }
+  st->x0_backward = st->depth == 2 && !st->defer_x0 && c->defer_x0 && lazy_q_width(c, m) && (m == 8 || m == 16);
   if (n_shifts < 2 && (st->depth < 3 || !st->defer_x0)) {  // a single system groups for X_0's sake or not at all
     for (bcg_field* q : st->Qfree) bcg_field_destroy(q);
     st->Qfree.clear();

@@ -248,6 +248,7 @@ struct MultiSteps {
   // XACC (deferred X_0, entry 0 only): before its steps, X_0 += P1 C_0 + q_0 C_1 + ... + q_{xacc-2} C_{xacc-1} -- the X_0 updates of
   // the group's earlier iterations, composed on the host onto the group's first P_0 (`p1`) and the normalised residual
   // blocks the kernel holds anyway.  xacc = number of those matrices (0: off); they follow entry 0's step matrices.
+  // p1 == nullptr (the spare-less form of a group of two, DeferredX0 in capi_solvers.hip): no P1 term, C_0 is not read.
   int xacc;
   const double2* p1;
 };
@@ -283,7 +284,7 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       tile_load<M>(x, sp.X[0], row, kq, ok);
     }
     Tile<M> p1;  // XACC: the group's first P_0, in flight while the residual blocks are normalised
-    if (NORM && steps.xacc > 0) tile_load<M>(p1, steps.p1, row, kq, ok);
+    if (NORM && steps.xacc > 0 && steps.p1 != nullptr) tile_load<M>(p1, steps.p1, row, kq, ok);
     if (NORM) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
@@ -298,7 +299,7 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       const double* cm = mat + 2 * (steps.last[0] - steps.first[0]) * MD;
       Acc<M> AX;
       acc_from_tile<M>(AX, x);
-      rmul_acc<M>(AX, p1, cm, lane);
+      if (steps.p1 != nullptr) rmul_acc<M>(AX, p1, cm, lane);
 #pragma unroll
       for (int j = 0; j + 1 < NS; ++j)
         if (j + 1 < steps.xacc) rmul_acc<M>(AX, q[j], cm + (j + 1) * MD, lane);

@@ -958,12 +958,18 @@ def test_grouping_randomised_schedules(bc, orc, monkeypatch):
             assert rel_err(a[s], o["X"][s]) < 1e-10, (what, s)
 
 
+@pytest.mark.parametrize("defer_x0", [0, 1], ids=["x0-every-iteration", "x0-deferred"])
 @pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 4), (8, [32, 4, 4, 8], 4)], ids=["m16", "m8"])
-def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypatch):
+def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, defer_x0, monkeypatch):
     """Capacity mode groups the shift updates over two iterations: that depth needs no memory (the phase B that closes a
     pair writes the new residual block over T and a released buffer becomes the next T).  Bit-identical to the ungrouped
-    solver in the same mode, for even and odd iteration counts and with the caller's B consumed or kept."""
+    solver in the same mode, for even and odd iteration counts and with the caller's B consumed or kept.
+    x0-deferred (the default): X_0's update of a pair's first iteration waits for the closing pass too, in the spare-less
+    form (DeferredX0 in capi_solvers.hip: the lost P_0 is recovered from the next one and the residual block) -- no memory
+    either; the first iteration of a pair then moves three field passes for shift 0 instead of five, X_0 agrees to
+    rounding, everything else stays bit-identical."""
     monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    monkeypatch.setenv("BCG_DEFER_X0", str(defer_x0))
     shifts, mass = [0.0, 1e-3, 0.1], 0.2
     U = orc.fill_gauge(dims, 71)
     Bh = orc.fill_field(m, int(np.prod(dims)), 72)
@@ -987,8 +993,19 @@ def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, monkeypa
         b, rb, pb, mem_b, Bb = run(0, iters, consume)
         assert ra == rb and mem_a == mem_b
         for s in range(len(shifts)):
-            assert np.array_equal(a[s], b[s]), (iters, consume, s)
+            if s == 0 and defer_x0:
+                assert rel_err(a[0], b[0]) < 1e-13, (iters, consume)
+            else:
+                assert np.array_equal(a[s], b[s]), (iters, consume, s)
         assert pa.get("phaseC_multi2", {}).get("count", 0) == iters // 2 and "phaseC_multi4" not in pa
+        assert pa.get("phaseC_p0", {}).get("count", 0) == (iters // 2 if defer_x0 else 0) and "phaseC_p0" not in pb
+        if iters >= 2:
+            # a pair moves 5 + (2 + 4 S) field passes, 3 + (2 + 4 S) with X_0 deferred (no spare field read); a plain iteration 1 + 4 S
+            S = len(shifts)
+            per_pass = pb["phaseC"]["bytes"] / (iters * (1 + 4 * S))
+            moved = sum(v["bytes"] for k, v in pa.items() if k.startswith("phaseC"))
+            want = (iters // 2) * ((3 if defer_x0 else 5) + 2 + 4 * S) + (iters % 2) * (1 + 4 * S)
+            assert moved == pytest.approx(per_pass * want, rel=1e-9)
         if not consume:
             assert np.array_equal(Ba, Bh) and np.array_equal(Bb, Bh)  # the rotation of T, Q never touches the caller's B
     o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=6)

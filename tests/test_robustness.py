@@ -149,6 +149,44 @@ def test_error_inside_a_group_of_a_single_system(bc, m, dims, depth, monkeypatch
             assert pa["phaseC_p0"]["count"] >= 1 and np.abs(a).max() > 0
 
 
+@pytest.mark.parametrize("m,dims,ring", [(16, [32, 4, 4, 12], 4), (8, [32, 4, 4, 8], 4)], ids=["m16", "m8"])
+def test_error_inside_a_pair_in_capacity_mode(bc, m, dims, ring, monkeypatch):
+    """Capacity mode groups in pairs and defers X_0 in the spare-less form: at a failure in the second iteration of a pair the
+    first one's X_0 update is pending and its P_0 is gone -- it is applied from the current P_0 and the kept residual block
+    (sbcgrq_flush_pending).  Every X_s equals what the ungrouped solver leaves at the same failure (X_0 to rounding)."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    shifts, mass = [0.0, 1e-3, 0.1], 0.2
+
+    def run(pair, fail_at):
+        monkeypatch.setenv("BCG_PAIR_SHIFTS", str(pair))
+        monkeypatch.setenv("BCG_DEBUG_FAIL_ITER", str(fail_at))
+        ctx = bc.Context(dims)
+        ctx.capacity_mode(ring)
+        ctx.profiling(True)
+        D = bc.dirac_op(ctx, mass, seed=95)
+        B = bc.block_fermion_field(ctx, m).setRandom(seed=96)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
+        with pytest.raises(bc.BlockCGError) as e:
+            st.iterate(12)
+        assert e.value.code == 6
+        st.end()
+        out, prof = [x.download() for x in X], ctx.profile()
+        ctx.close()
+        return out, prof
+
+    for fail_at in range(1, 6):
+        a, pa = run(4, fail_at)
+        b, pb = run(0, fail_at)
+        for s in range(len(shifts)):
+            assert np.isfinite(a[s]).all()
+            if s == 0:
+                assert rel_err(a[0], b[0]) < 1e-13, fail_at
+            else:
+                assert np.array_equal(a[s], b[s]), (fail_at, s)
+        assert pa.get("phaseC_p0", {}).get("count", 0) == fail_at // 2 and "phaseC_p0" not in pb
+
+
 def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypatch):
     """bcg_sbcgrq_begin allocates what the operator needs (tmp, scratch) BEFORE the optional residual buffers of the grouped
     shift updates.  With room for the base plan + 1.5 fields the default depth 4 (two extra fields) must fall back to depth 3
@@ -188,14 +226,15 @@ def test_optional_residual_buffers_never_cost_the_solve_its_memory(bc, monkeypat
     d, pd = run(3.25)    # both extra buffers and the spare fit: as without a limit
     assert pa == {"phaseC", "phaseC_multi3"}, pa            # 7 iterations = 3 + 3 + 1
     assert pb == {"phaseC_p0", "phaseC_multi4", "phaseC_multi3"}, pb   # 4 + 3, shift 0 inside a group as P_0 alone
-    assert pc == {"phaseC", "phaseC_multi2"}, pc            # 2 + 2 + 2 + 1
+    # 2 + 2 + 2 + 1: pairs defer X_0 without a spare field (the spare-less form), the odd last iteration is a plain one
+    assert pc == {"phaseC", "phaseC_multi2", "phaseC_p0"}, pc
     assert pd == pb
     for s in range(len(shifts)):
-        assert np.array_equal(a[s], c[s]) and np.array_equal(d[s], b[s])  # the grouping depth never changes the iterates
-        if s == 0:  # ... and deferring X_0 changes it by rounding only
-            assert rel_err(a[0], b[0]) < 1e-13
-        else:
-            assert np.array_equal(a[s], b[s])
+        assert np.array_equal(d[s], b[s])
+        if s == 0:  # deferring X_0 (either form) changes it by rounding only
+            assert rel_err(a[0], b[0]) < 1e-13 and rel_err(a[0], c[0]) < 1e-13
+        else:       # ... and the grouping depth never changes the iterates
+            assert np.array_equal(a[s], b[s]) and np.array_equal(a[s], c[s])
     # and a budget below the base plan is an error at begin, not a crash in the first iteration
     monkeypatch.setenv("BCG_DEBUG_FIELD_BUDGET", str(int(11.5 * field)))
     ctx = bc.Context(dims)
