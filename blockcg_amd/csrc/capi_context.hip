@@ -369,6 +369,7 @@ int bcg_context_create(bcg_context** out, int device, void* stream, int ndim, co
   if (const char* e = std::getenv("BCG_LAZY_Q")) c->lazy_q = std::atoi(e);  // 2: at m = 32 too (tuning)
   if (const char* e = std::getenv("BCG_PAIR_SHIFTS")) c->pair_shifts = std::atoi(e);  // depth (pair_shifts_depth)
   if (const char* e = std::getenv("BCG_DEFER_X0")) c->defer_x0 = std::atoi(e) != 0;   // deferred update of X_0 (DeferredX0)
+  if (const char* e = std::getenv("BCG_DEBUG_X0_COND_LIMIT")) c->x0_cond_limit = std::atof(e);  // test aid: 0 = the guard always refuses
   if (const char* e = std::getenv("BCG_RING_CHUNK")) c->ring_chunk_override = std::atoi(e);
   if (const char* e = std::getenv("BCG_DEBUG_FIELD_BUDGET")) c->debug_field_budget = static_cast<size_t>(std::atoll(e));
   if (const char* e = std::getenv("BCG_DEBUG_FAIL_ITER")) c->debug_fail_iter = std::atoi(e);

@@ -686,7 +686,7 @@ int sbcgrq_iteration(bcg_sbcgrq_state* st, bcg_sbcgrq_trace* trace, bool more_fo
         f2 += std::norm(st->rho(i, j));
         g2 += std::norm(rinv(i, j));
       }
-    x0_backward = x0_waits = std::sqrt(f2 * g2) <= 64.0 * m;  // (NaN compares false: the plain update)
+    x0_backward = x0_waits = std::sqrt(f2 * g2) <= c->x0_cond_limit * m;  // (NaN compares false: the plain update)
   }
   // (with shift 0 alone left -- a single system, or the tail of a solve whose shifted systems have converged -- a group
   // is worth opening only for X_0's sake, and only if it can run to three iterations: pair_shifts_depth)

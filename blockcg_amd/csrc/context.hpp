@@ -71,6 +71,7 @@ struct bcg_context {
   int lazy_q = 1;                        // SBCGrQ: deferred normalisation of Q (phase_B in capi_solvers.hip; BCG_LAZY_Q)
   int pair_shifts = 4;                   // SBCGrQ: shifts >= 1 updated this many iterations at a time (pair_shifts_depth; BCG_PAIR_SHIFTS)
   bool defer_x0 = true;                  // SBCGrQ: X_0's updates wait for the pass that closes a group too (DeferredX0; BCG_DEFER_X0)
+  double x0_cond_limit = 64.0;           // ... spare-less form: taken while ||rho||_F ||rho^-1||_F <= limit * m (BCG_DEBUG_X0_COND_LIMIT: test aid)
   size_t debug_field_budget = 0;         // test aid (BCG_DEBUG_FIELD_BUDGET, bytes): field allocations beyond it fail like an out-of-memory
   size_t field_bytes_live = 0;           // bytes of the fields this context holds (incl. tmp and the solver's work fields)
   int debug_fail_iter = 0;               // test aid (BCG_DEBUG_FAIL_ITER): SBCGrQ iteration whose Gram matrix after phase B is made non-finite

@@ -1012,6 +1012,15 @@ def test_grouped_shift_updates_in_capacity_mode(bc, orc, m, dims, ring, defer_x0
     a, _, _, _, _ = run(4, 6, True)
     for s in range(len(shifts)):
         assert rel_err(a[s], o["X"][s]) < 1e-10
+    if defer_x0:
+        # the guard of the spare-less form (||rho||_F ||rho^-1||_F <= limit * m): refused, the iteration runs the plain
+        # five-pass update and everything is bit-identical to the ungrouped solver again
+        monkeypatch.setenv("BCG_DEBUG_X0_COND_LIMIT", "0")
+        g, rg, pg, _, _ = run(4, 6, True)
+        b, rb, _, _, _ = run(0, 6, True)
+        assert rg == rb and "phaseC_p0" not in pg and pg["phaseC_multi2"]["count"] == 3
+        for s in range(len(shifts)):
+            assert np.array_equal(g[s], b[s]), s
 
 
 def test_grouped_shift_updates_with_more_shifts_than_one_launch_holds(bc, orc, monkeypatch):
