@@ -133,7 +133,7 @@ struct DeferredIteration {
   bool x0_backward = false;      //   ... and its P_0 was NOT kept: the spare-less form of a group of two (DeferredX0)
 };
 
-// Deferred update of X_0 (m = 8, 16 outside capacity mode; BCG_DEFER_X0=0 switches it off).  X_0 is never read by the
+// Deferred update of X_0 (m = 8, 16; BCG_DEFER_X0=0 switches it off; capacity mode: the spare-less form below).  X_0 is never read by the
 // iteration (:145 is its only appearance), so like the X_s of the shifted systems it can wait for the pass that closes a
 // group of iterations -- but P_0 cannot (the next operator application reads it), and X_0 += P_0 A0 needs the P_0 of ITS
 // iteration.  With P_0^(i+1) = P_0^(i) R_i + q_i the group's updates collapse onto the group's FIRST P_0 and the

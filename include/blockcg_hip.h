@@ -138,7 +138,8 @@ int bcg_capacity_mode(bcg_context* ctx, int ring_slices);
  * each deferred iteration (two at a time, as in capacity mode and at m = 32, need none: T doubles as the second buffer),
  * and X_0 (:145) with them, which needs the group's first P_0 kept in the spare field while P_0 moves on.  A single
  * system (n_shifts = 1) groups for X_0's sake alone, in threes or fours or not at all.  X_s, s >= 1, the residuals and
- * the iteration count are bit-identical to the ungrouped solver, X_0 agrees to rounding (1e-13); a solve that cannot
+ * the iteration count are bit-identical to the ungrouped solver, X_0 agrees to rounding (1e-13); capacity mode (groups of
+ * two) defers X_0 as well, in a form that needs no field; a solve that cannot
  * allocate the buffers runs with fewer; BCG_PAIR_SHIFTS=0 at context creation switches the grouping off, BCG_DEFER_X0=0
  * the deferred X_0 update.  Host arithmetic only. */
 int bcg_sbcgrq_device_bytes(const bcg_context* ctx, int m, int n_shifts, int consume_B, size_t* bytes_out);
