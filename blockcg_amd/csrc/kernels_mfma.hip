@@ -95,6 +95,94 @@ __global__ void __launch_bounds__(256) k_phaseB(int64_t rows, const double2* Q, 
   gram_fold<M * M>(gf, partials, tid, NW * 64);
 }
 
+// Phase B with its stores BATCHED (round 5; tools/microbench/rw_phased.hip, and k_phaseC_p0_batched below for the form): a
+// block of 8 waves owns chunks of N consecutive tiles, wave w takes tiles w, w + 8, ... of the chunk with the next one's
+// loads in flight, leaves each new tile in LDS in the field's own layout (rows padded by one element: the same buffer is
+// the transposition source of the fused Gram product), and after a barrier the block writes the chunk, contiguous.  The
+// first tiles of the block's next chunk are in flight during the stores.  In place (Qout == Q) and over T are safe: a block
+// has read its whole chunk of both before it writes.  Same products as k_phaseB; the Gram partial sums run over other
+// tiles per wave and block (a different, equally valid summation order).  rows must be a multiple of 16 N.
+template <int M, int N>
+__global__ void __launch_bounds__(512) k_phaseB_batched(int64_t rows, const double2* Q, const double2* T,
+                                                        const double2* __restrict__ negalpha, double2* __restrict__ partials,
+                                                        GramFold gf, const double2* __restrict__ rinv, double2* Qout) {
+  static_assert(M == 16, "the batched phase B is instantiated for m = 16");
+  constexpr int NW = 8;
+  constexpr int RS = M + 1;  // double2 per staged row (= k_phaseB's transposition row, M * 2 + 2 doubles)
+  constexpr int MDs = (MatLds<M>::DOUBLES + 1) & ~1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* Ml = smem;
+  double* Mr = smem + MDs;
+  double2* const stage = reinterpret_cast<double2*>(smem + 2 * MDs);  // N tiles of 16 rows x RS; the Gram reduction's buffer at the end
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(Ml, negalpha, tid, NW * 64);
+  if (rinv) stage_matrix<M>(Mr, rinv, tid, NW * 64);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  GramAcc<M> G;
+  gram_zero(G);
+  const int64_t nchunks = rows / (16 * N);
+  constexpr int PER = N / NW;
+  Tile<M> t, q;
+  if (blockIdx.x < nchunks) {
+    tile_load<M>(t, T, (static_cast<int64_t>(blockIdx.x) * N + wave) * 16 + r, kq, true);
+    tile_load<M>(q, Q, (static_cast<int64_t>(blockIdx.x) * N + wave) * 16 + r, kq, true);
+  }
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t t0 = c * N;
+    const bool more = c + gridDim.x < nchunks;  // block-uniform
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = wave + NW * j;
+      Tile<M> tn, qn;
+      if (j + 1 < PER) {
+        tile_load<M>(tn, T, (t0 + i + NW) * 16 + r, kq, true);
+        tile_load<M>(qn, Q, (t0 + i + NW) * 16 + r, kq, true);
+      } else if (more) {
+        tile_load<M>(tn, T, ((c + gridDim.x) * N + wave) * 16 + r, kq, true);
+        tile_load<M>(qn, Q, ((c + gridDim.x) * N + wave) * 16 + r, kq, true);
+      }
+      if (rinv) {
+        Acc<M> A0;
+        acc_zero<M>(A0);
+        rmul_acc<M>(A0, q, Mr, lane);
+        tile_from_acc<M>(q, A0);
+      }
+      Acc<M> A;
+      acc_from_tile<M>(A, q);
+      rmul_acc<M>(A, t, Ml, lane);
+      tile_from_acc<M>(q, A);
+      double2* const mine = stage + (i * 16) * RS;
+#pragma unroll
+      for (int s = 0; s < M / 4; ++s) mine[r * RS + 4 * s + kq] = q.v[s];
+      // same wave wrote and reads (LDS operations of one wave are in order): rows 4g + (lane >> 4), column lane & 15
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double2 a = mine[(4 * g + (lane >> 4)) * RS + (lane & 15)];
+        gram_step<M>(G, &a, &a);
+      }
+      if (j + 1 < PER || more) {
+        t = tn;
+        q = qn;
+      }
+    }
+    __syncthreads();
+    double2* const out = Qout + t0 * 16 * M;
+    constexpr int ELEMS = N * 16 * M;
+#pragma unroll 4
+    for (int e = tid; e < ELEMS; e += NW * 64) {
+      const double2 v = stage[(e / M) * RS + (e % M)];
+      dv2 w;
+      w.x = v.x;
+      w.y = v.y;
+      __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(out + e));
+    }
+    __syncthreads();
+  }
+  gram_block_store<M, NW>(G, reinterpret_cast<double*>(stage), partials, tid, gf.out != nullptr);
+  gram_fold<M * M>(gf, partials, tid, NW * 64);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Phase C:  Q <- Q*Rinv ; for each active shift s:  X_s += P_s*A_s ;  P_s <- P_s*B_s + Q.
 // mats: [Rinv, A_0, B_0, A_1, B_1, ...] complex column-major, consecutive in device memory.
@@ -225,6 +313,79 @@ __global__ void __launch_bounds__(256) k_phaseC_p0(int64_t rows, const double2* 
       q = qn;
       p = pn;
     }
+  }
+}
+
+// The same pass with its stores BATCHED (experiment of round 5, tools/microbench/rw_phased.hip: a streaming kernel with two
+// arrays read and one written gains 10-15 % when every block reads a contiguous chunk, keeps the results in LDS and writes
+// them out together).  A block of 8 waves owns chunks of N consecutive tiles: wave w multiplies tiles w, w + 8, ... of the
+// chunk (the next one's loads in flight), leaves each result in LDS in the field's own layout (rows padded by one element
+// against bank conflicts), and after a barrier the block writes the chunk -- N x 4 KB (m = 16), contiguous, 1 KB per wave
+// instruction.  In place is safe: a block has read its whole chunk of P before it writes it.  Same products on the same
+// values: bit-identical to k_phaseC_p0.  rows must be a multiple of 16 N.
+template <int M, int N>
+__global__ void __launch_bounds__(512) k_phaseC_p0_batched(int64_t rows, const double2* __restrict__ Q, const double2* P, double2* Pout,
+                                                           const double2* __restrict__ mats) {
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
+  constexpr int RS = M + 1;                       // row stride of the staged tiles, in double2
+  double2* const stage = reinterpret_cast<double2*>(smem + 2 * MD);  // N tiles of 16 rows x RS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(smem, mats, tid, NW * 64);
+  stage_matrix<M>(smem + MD, mats + static_cast<int64_t>(M) * M, tid, NW * 64);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t nchunks = rows / (16 * N);
+  constexpr int PER = N / NW;
+  Tile<M> q, p;
+  if (blockIdx.x < nchunks) {
+    tile_load<M>(q, Q, (static_cast<int64_t>(blockIdx.x) * N + wave) * 16 + r, kq, true);
+    tile_load<M>(p, P, (static_cast<int64_t>(blockIdx.x) * N + wave) * 16 + r, kq, true);
+  }
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t t0 = c * N;
+    const bool more = c + gridDim.x < nchunks;  // block-uniform: the next chunk's first tiles are in flight during the stores
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = wave + NW * j;
+      Tile<M> qn, pn;
+      if (j + 1 < PER) {
+        tile_load<M>(qn, Q, (t0 + i + NW) * 16 + r, kq, true);
+        tile_load<M>(pn, P, (t0 + i + NW) * 16 + r, kq, true);
+      } else if (more) {
+        tile_load<M>(qn, Q, ((c + gridDim.x) * N + wave) * 16 + r, kq, true);
+        tile_load<M>(pn, P, ((c + gridDim.x) * N + wave) * 16 + r, kq, true);
+      }
+      Acc<M> A;
+      acc_zero<M>(A);
+      rmul_acc<M>(A, q, smem, lane);
+      tile_from_acc<M>(q, A);
+      Acc<M> AP;
+      acc_from_tile<M>(AP, q);
+      rmul_acc<M>(AP, p, smem + MD, lane);
+      tile_from_acc<M>(p, AP);
+      double2* const dst = stage + (i * 16 + r) * RS + kq;
+#pragma unroll
+      for (int s = 0; s < M / 4; ++s) dst[4 * s] = p.v[s];
+      if (j + 1 < PER || more) {
+        q = qn;
+        p = pn;
+      }
+    }
+    __syncthreads();
+    // the chunk, contiguous: element e of the chunk = row e / M (of N x 16), column e % M
+    double2* const out = Pout + t0 * 16 * M;
+    constexpr int ELEMS = N * 16 * M;
+#pragma unroll 4
+    for (int e = tid; e < ELEMS; e += NW * 64) {
+      const double2 v = stage[(e / M) * RS + (e % M)];
+      dv2 w;
+      w.x = v.x;
+      w.y = v.y;
+      __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(out + e));
+    }
+    __syncthreads();
   }
 }
 
@@ -479,6 +640,16 @@ __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, cons
 
 }  // namespace
 
+// The streaming row kernels at m = 16 (phase B, k_phaseC_p0) batch their stores per chunk of tiles through LDS (k_phaseB_batched).
+// BCG_ROW_BATCHED=0 (read once per process) keeps the plain kernels: the A/B of record.
+static bool row_batched() {
+  static const bool on = [] {
+    const char* e = std::getenv("BCG_ROW_BATCHED");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  return on;
+}
+
 bool mfma_width(int m) { return m == 8 || m == 16 || m == 32; }  // declared in kernels.hpp
 bool mfma_rows_width(int m) { return m == 8 || m == 16 || m == 32; }  // right-multiply kernels (phase C, K5, K6)
 int phaseC_max_shifts(int m, bool applies_rinv) {
@@ -495,6 +666,15 @@ int launch_phaseB(hipStream_t s, int m, int64_t rows, double2* Q, const double2*
     hipLaunchKernelGGL(k_phaseB8, dim3(grid), dim3(256), lds, s, gf, rows, Q, T, negalpha, partials, rinv, Qout);
   } else if (m == 16) {
     constexpr int M = 16;
+    // stores batched per chunk of 32 tiles: 6.68 against 7.42 ms at 64^4 (profiles/r05_batched_stores.txt); BCG_ROW_BATCHED=0: the plain kernel
+    if (row_batched() && rows % (16 * 32) == 0 && max_blocks >= 8) {
+      constexpr int N = 32;
+      const size_t ldsb = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * 2 + sizeof(double2) * N * 16 * (M + 1);
+      const int grid8 = static_cast<int>(std::min<int64_t>(rows / (16 * N), std::min(256, max_blocks)));
+      allow_lds(k_phaseB_batched<M, N>, ldsb);
+      hipLaunchKernelGGL((k_phaseB_batched<M, N>), dim3(grid8), dim3(512), ldsb, s, rows, Q, T, negalpha, partials, gf, rinv, Qout);
+      return grid8;
+    }
     const size_t lds = sizeof(double) * (((MatLds<M>::DOUBLES + 1) & ~1) * (rinv ? 2 : 1) + 4 * 16 * (2 * M + 2));  // TRN 2176 >= RED 2048
     hipLaunchKernelGGL((k_phaseB<M>), dim3(grid), dim3(256), lds, s, rows, Q, T, negalpha, partials, gf, rinv, Qout);
   } else {
@@ -544,6 +724,16 @@ void launch_phaseC_p0(hipStream_t s, int m, int64_t rows, const double2* Q, cons
                       int max_blocks) {
   // profiles/r05_phaseC_p0.txt (64^4, m = 16): the next tile's loads in flight during the products and two blocks per CU,
   // 7.26 ms per launch; without the prefetch 7.56-7.63 ms at 1024, 1536 or 2048 blocks, with it at 1024 blocks 7.84
+  // stores batched per chunk of 32 tiles, one 8-wave block per CU: 6.73 against 7.25 ms at 64^4 (chunks of 16, two blocks
+  // per CU: no gain; profiles/r05_batched_stores.txt); BCG_ROW_BATCHED=0: the plain kernel
+  if (m == 16 && row_batched() && rows % (16 * 32) == 0 && max_blocks >= 8) {
+    constexpr int M = 16, N = 32;
+    const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * 2 + sizeof(double2) * N * 16 * (M + 1);
+    const int grid8 = static_cast<int>(std::min<int64_t>(rows / (16 * N), std::min(256, max_blocks)));
+    allow_lds(k_phaseC_p0_batched<M, N>, lds);
+    hipLaunchKernelGGL((k_phaseC_p0_batched<M, N>), dim3(grid8), dim3(512), lds, s, rows, Q, P, Pout, mats);
+    return;
+  }
   const int grid = grid_tiles((rows + 15) / 16, 4, max_blocks < 512 ? max_blocks : 512);
   if (m == 8) {
     const size_t lds = sizeof(double) * ((MatLds<8>::DOUBLES + 1) & ~1) * 2;
