@@ -726,6 +726,7 @@ void launch_phaseC_p0(hipStream_t s, int m, int64_t rows, const double2* Q, cons
   // 7.26 ms per launch; without the prefetch 7.56-7.63 ms at 1024, 1536 or 2048 blocks, with it at 1024 blocks 7.84
   // stores batched per chunk of 32 tiles, one 8-wave block per CU: 6.73 against 7.25 ms at 64^4 (chunks of 16, two blocks
   // per CU: no gain; profiles/r05_batched_stores.txt); BCG_ROW_BATCHED=0: the plain kernel
+  // (m = 8 at 32^4, config 1: the batched form is slower, 0.179 against 0.169 ms -- profiles/r05_batched_stores.txt)
   if (m == 16 && row_batched() && rows % (16 * 32) == 0 && max_blocks >= 8) {
     constexpr int M = 16, N = 32;
     const size_t lds = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) * 2 + sizeof(double2) * N * 16 * (M + 1);
