@@ -499,6 +499,7 @@ k_phaseC_multi(int64_t rows, MultiQ qs, ShiftPtrs sp, int nent, MultiSteps steps
       }
     }
   };
+  // (one contiguous run of tiles per block instead of this interleaved map: no gain at depth 2 or 4, profiles/r05_batched_stores.txt)
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
     if ((tile + 1) * 16 <= rows) body(tile, std::true_type{});
     else body(tile, std::false_type{});
