@@ -14,7 +14,7 @@ import re
 import sys
 
 NAMES = [(r"k_phaseC_multi<\d+, \d+, 2[,>]", "phaseC_multi2"), (r"k_phaseC_multi<\d+, \d+, 3[,>]", "phaseC_multi3"),
-         (r"k_phaseC_multi<\d+, \d+, 4[,>]", "phaseC_multi4"), (r"k_phaseC_p0<", "phaseC_p0"), (r"k_phaseC<", "phaseC"), (r"k_phaseB", "phaseB"), (r"k_hop4b<\d+, 0, false", "hop"), (r"k_hop4b<\d+, 1, true", "hop_shifted_gram"),
+         (r"k_phaseC_multi<\d+, \d+, 4[,>]", "phaseC_multi4"), (r"k_phaseC_p0(_batched)?<", "phaseC_p0"), (r"k_phaseC<", "phaseC"), (r"k_phaseB", "phaseB"), (r"k_hop4b<\d+, 0, false", "hop"), (r"k_hop4b<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4b<\d+, 1, false", "hop_shifted"), (r"k_hop4c<\d+, 0, false", "hop"), (r"k_hop4c<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4c<\d+, 1, false", "hop_shifted"), (r"k_hop4<\d+, 0, false", "hop"), (r"k_hop4<\d+, 1, true", "hop_shifted_gram"),
          (r"k_hop4<\d+, 1, false", "hop_shifted"), (r"k_hop_fast<\d+, 0", "hop"), (r"k_hop_fast<\d+, 1, true", "hop_shifted_gram")]

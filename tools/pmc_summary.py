@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSV output per kernel: python tools/pmc_summary.py <dir> [<dir> ...]"""
+"""Summarise rocprofv3 --pmc CSV output per kernel: python tools/pmc_summary.py <dir> [<dir> ...]
+(the newest pass of each directory only: gpurun merges every call's files back, so a local copy may hold older passes too)"""
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+    for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
         for r in csv.DictReader(open(f)):
             m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
