@@ -544,6 +544,78 @@ __global__ void __launch_bounds__(256) k_rmul_mfma(int64_t rows, double2* __rest
   }
 }
 
+// ... with the stores batched per chunk of N tiles through LDS (m = 16; the form of k_phaseC_p0_batched: 8 waves, the next
+// tile's loads in flight, the first tiles of the block's next chunk in flight during the stores).  y is updated in place: a
+// block has read its whole chunk before it writes it.  Same products: bit-identical to k_rmul_mfma.  rows % (16 N) == 0.
+template <int M, int MODE, int N>
+__global__ void __launch_bounds__(512) k_rmul_mfma_batched(int64_t rows, double2* y, const double2* __restrict__ x,
+                                                           const double2* __restrict__ Cg, double b) {
+  constexpr int NW = 8;
+  constexpr int MD = (MatLds<M>::DOUBLES + 1) & ~1;
+  constexpr int RS = M + 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double2* const stage = reinterpret_cast<double2*>(smem + MD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_matrix<M>(smem, Cg, tid, NW * 64);
+  __syncthreads();
+  const int r = lane & 15, kq = lane >> 4;
+  const int64_t nchunks = rows / (16 * N);
+  constexpr int PER = N / NW;
+  Tile<M> ty, tx;
+  if (blockIdx.x < nchunks) {
+    const int64_t row = (static_cast<int64_t>(blockIdx.x) * N + wave) * 16 + r;
+    tile_load<M>(ty, y, row, kq, true);
+    if (MODE != RMUL_MUL) tile_load<M>(tx, x, row, kq, true);
+  }
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t t0 = c * N;
+    const bool more = c + gridDim.x < nchunks;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = wave + NW * j;
+      Tile<M> tyn, txn;
+      if (j + 1 < PER || more) {
+        const int64_t nrow = (j + 1 < PER ? t0 + i + NW : (c + gridDim.x) * N + wave) * 16 + r;
+        tile_load<M>(tyn, y, nrow, kq, true);
+        if (MODE != RMUL_MUL) tile_load<M>(txn, x, nrow, kq, true);
+      }
+      Acc<M> A;
+      if (MODE == RMUL_ADD) {
+        acc_from_tile<M>(A, ty);
+        rmul_acc<M>(A, tx, smem, lane);
+      } else if (MODE == RMUL_XPAY) {
+#pragma unroll
+        for (int s = 0; s < M / 4; ++s) tx.v[s] = make_double2(b * tx.v[s].x, b * tx.v[s].y);
+        acc_from_tile<M>(A, tx);
+        rmul_acc<M>(A, ty, smem, lane);
+      } else {
+        acc_zero<M>(A);
+        rmul_acc<M>(A, ty, smem, lane);
+      }
+      tile_from_acc<M>(ty, A);
+      double2* const dst = stage + (i * 16 + r) * RS + kq;
+#pragma unroll
+      for (int s = 0; s < M / 4; ++s) dst[4 * s] = ty.v[s];
+      if (j + 1 < PER || more) {
+        ty = tyn;
+        if (MODE != RMUL_MUL) tx = txn;
+      }
+    }
+    __syncthreads();
+    double2* const out = y + t0 * 16 * M;
+    constexpr int ELEMS = N * 16 * M;
+#pragma unroll 4
+    for (int e = tid; e < ELEMS; e += NW * 64) {
+      const double2 v = stage[(e / M) * RS + (e % M)];
+      dv2 w;
+      w.x = v.x;
+      w.y = v.y;
+      __builtin_nontemporal_store(w, reinterpret_cast<dv2*>(out + e));
+    }
+    __syncthreads();
+  }
+}
+
 // Stand-alone Gram product a^dagger b: coalesced loads already have (row = l>>4, col = l&15) ownership.
 template <int M>
 __global__ void __launch_bounds__(256) k_gram_mfma(int64_t rows, const double2* __restrict__ a, const double2* __restrict__ b,
@@ -805,6 +877,23 @@ void launch_rmul_mfma(hipStream_t s, int m, int64_t rows, double2* y, const doub
     if (mode == RMUL_ADD) hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_ADD>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b);       \
     else if (mode == RMUL_XPAY) hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_XPAY>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b); \
     else hipLaunchKernelGGL((k_rmul_mfma<M, RMUL_MUL>), dim3(grid), dim3(256), lds, s, rows, y, x, Cd, b);       \
+  }
+  // m = 16: stores batched per chunk of 32 tiles (k_phaseC_p0_batched's form; BCG_ROW_BATCHED=0: the plain kernel)
+  if (m == 16 && row_batched() && rows % (16 * 32) == 0 && max_blocks >= 8) {
+    constexpr int M = 16, N = 32;
+    const size_t ldsb = sizeof(double) * ((MatLds<M>::DOUBLES + 1) & ~1) + sizeof(double2) * N * 16 * (M + 1);
+    const int grid8 = static_cast<int>(std::min<int64_t>(rows / (16 * N), std::min(256, max_blocks)));
+    if (mode == RMUL_ADD) {
+      allow_lds(k_rmul_mfma_batched<M, RMUL_ADD, N>, ldsb);
+      hipLaunchKernelGGL((k_rmul_mfma_batched<M, RMUL_ADD, N>), dim3(grid8), dim3(512), ldsb, s, rows, y, x, Cd, b);
+    } else if (mode == RMUL_XPAY) {
+      allow_lds(k_rmul_mfma_batched<M, RMUL_XPAY, N>, ldsb);
+      hipLaunchKernelGGL((k_rmul_mfma_batched<M, RMUL_XPAY, N>), dim3(grid8), dim3(512), ldsb, s, rows, y, x, Cd, b);
+    } else {
+      allow_lds(k_rmul_mfma_batched<M, RMUL_MUL, N>, ldsb);
+      hipLaunchKernelGGL((k_rmul_mfma_batched<M, RMUL_MUL, N>), dim3(grid8), dim3(512), ldsb, s, rows, y, x, Cd, b);
+    }
+    return;
   }
   if (m == 8) BCG_RMUL(8) else if (m == 16) BCG_RMUL(16) else BCG_RMUL(32)
 #undef BCG_RMUL
