@@ -714,13 +714,10 @@ __global__ void __launch_bounds__(256) k_phaseB8(GramFold gf, int64_t rows, cons
 }  // namespace
 
 // The streaming row kernels at m = 16 (phase B, k_phaseC_p0) batch their stores per chunk of tiles through LDS (k_phaseB_batched).
-// BCG_ROW_BATCHED=0 (read once per process) keeps the plain kernels: the A/B of record.
-static bool row_batched() {
-  static const bool on = [] {
-    const char* e = std::getenv("BCG_ROW_BATCHED");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  return on;
+// BCG_ROW_BATCHED=0 keeps the plain kernels: the A/B of record.
+static bool row_batched() {  // (read per launch, not cached: the tests switch it inside one process)
+  const char* e = std::getenv("BCG_ROW_BATCHED");
+  return e ? std::atoi(e) != 0 : true;
 }
 
 bool mfma_width(int m) { return m == 8 || m == 16 || m == 32; }  // declared in kernels.hpp

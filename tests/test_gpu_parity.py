@@ -911,6 +911,48 @@ def test_single_system_groups_for_the_deferred_x0_update(bc, orc, m, dims, monke
         assert rel_err(a[s], o["X"][s]) < 1e-10
 
 
+def test_batched_row_kernels_against_the_plain_ones(bc, orc, monkeypatch):
+    """m = 16, row counts that are multiples of 512: phase B, k_phaseC_p0 and the right-multiplications K5 / K6 keep a chunk
+    of 32 tiles in LDS and write it out together (kernels_mfma.hip: k_phaseB_batched, k_phaseC_p0_batched, k_rmul_mfma_batched).
+    Same products on the same values: K5 / K6 are bit-identical to the plain kernels (BCG_ROW_BATCHED=0); in the solver phase
+    B's Gram partial sums take another order, so a solve agrees to rounding -- and with the oracle as before."""
+    monkeypatch.setenv("BCG_HOP_PATCH", "16,2,2")
+    m, dims, mass, shifts = 16, [16, 8, 8, 8], 0.2, [0.0, 1e-3, 0.1, 2.0]
+    assert (int(np.prod(dims)) * 3) % 512 == 0
+    U = orc.fill_gauge(dims, 91)
+    Bh = orc.fill_field(m, int(np.prod(dims)), 92)
+    Xh = orc.fill_field(m, int(np.prod(dims)), 93)
+    rng = np.random.default_rng(94)
+    C = (rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))) * 0.2
+    out = {}
+    for batched in ("1", "0"):
+        monkeypatch.setenv("BCG_ROW_BATCHED", batched)
+        ctx = bc.Context(dims)
+        ctx.profiling(True)
+        x = bc.block_fermion_field(ctx, m, Xh)
+        y = bc.block_fermion_field(ctx, m, Bh)
+        y.add(x, C)                # K5, inc/fields.hpp:70-77
+        k5 = y.download()
+        y.rescale_add(C, x, 0.5)   # K6, inc/fields.hpp:79-90
+        k6 = y.download()
+        D = bc.dirac_op(ctx, mass, U=U)
+        B = bc.block_fermion_field(ctx, m, Bh)
+        X = [bc.block_fermion_field(ctx, m) for _ in shifts]
+        st = bc.SBCGrQState(X, B, D, shifts, 0.0, 0.0)
+        st.iterate(9)
+        res = st.residual
+        st.end()
+        out[batched] = (k5, k6, [f.download() for f in X], res)
+        ctx.close()
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    for s in range(len(shifts)):
+        assert rel_err(out["1"][2][s], out["0"][2][s]) < 1e-12, s
+    assert abs(out["1"][3] - out["0"][3]) <= 1e-12 * out["0"][3]
+    o = orc.sbcgrq(U, dims, mass, Bh, shifts, 0.0, 0.0, max_iterations=9)
+    for s in range(len(shifts)):
+        assert rel_err(out["1"][2][s], o["X"][s]) < 1e-10
+
+
 def test_grouping_randomised_schedules(bc, orc, monkeypatch):
     """Seeded random schedules through the solver's state machine: width 8 / 16, 1 ... 8 shifts of random size (so that some
     retire early, some never), group depth 2 ... 4, X_0 deferred or not, the iterations asked for in random pieces (a piece
